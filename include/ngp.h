@@ -1,0 +1,226 @@
+/*
+ * ngp.h — C-ABI of the MI355X-native GP inference core ("libngp").
+ *
+ * This is the drop-in boundary for the ONE hot path NowcastAutoGP delegates to
+ * AutoGP.jl: per-particle covariance assembly from a kernel tree -> Cholesky ->
+ * log-marginal-likelihood -> posterior-predictive solves, batched over SMC
+ * particles x nowcast scenarios.  Reference call sites (paths relative to the
+ * reference checkout):
+ *     src/make_and_fit_model.jl:104-111   GPModel(...), linear_schedule, fit_smc!
+ *     src/forecasting.jl:159-160,178-180  predict_mvn + rand
+ *     src/forecasting.jl:246-262          GPModel(dict), add_data!, maybe_resample!,
+ *                                         mcmc_structure!, mcmc_parameters!
+ * The reference has no FFI of its own (it is pure Julia on AutoGP.jl); the
+ * entry points below are what a Julia `ccall` / Python `ctypes` shim binds in
+ * place of AutoGP's internal covariance/Cholesky/logpdf arithmetic.  See
+ * INTEGRATION.md for the binding stubs.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns an
+ *     ngp_status (0 = ok, <0 = bad argument, >0 = HIP runtime error code).
+ *   - all pointers are caller-owned HOST memory, valid for the duration of the
+ *     call (or, for staged jobs, until ngp_job_run returns for inputs and
+ *     ngp_job_fetch returns for outputs); the library retains none of them.
+ *   - Float64 everywhere (src/forecasting.jl:175); dense outputs are row-major
+ *     and symmetric where that applies, so Julia's column-major view is the same
+ *     matrix.
+ *   - numerical failure is reported PER ITEM in info[] with LAPACK potrf
+ *     semantics (k > 0: leading minor k is not positive definite), which the
+ *     shim rethrows as PosDefException(k) (src/make_and_fit_model.jl:26-28).
+ *   - re-entrant: may be entered concurrently from many host threads
+ *     (Threads.@spawn per scenario, src/forecasting.jl:244-245); calls on one
+ *     ctx are serialised by a blocking mutex, never a spin.
+ */
+#ifndef NGP_H
+#define NGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- kernel grammar: opcode numbering follows AutoGP.GP.GPConfig ---------
+ * (docs/src/vignettes/setting-priors.md:229-236 in the reference).            */
+enum {
+    NGP_OP_CONSTANT     = 1, /* params: value                                 */
+    NGP_OP_LINEAR       = 2, /* params: intercept, bias, amplitude            */
+    NGP_OP_SQEXP        = 3, /* params: lengthscale, amplitude                */
+    NGP_OP_GAMMAEXP     = 4, /* params: lengthscale, gamma, amplitude         */
+    NGP_OP_PERIODIC     = 5, /* params: lengthscale, period, amplitude        */
+    NGP_OP_PLUS         = 6, /* binary, no params                             */
+    NGP_OP_TIMES        = 7, /* binary, no params                             */
+    NGP_OP_CHANGEPOINT  = 8  /* binary, params: location, scale               */
+};
+
+#define NGP_MAX_OPS    64  /* nodes per kernel tree                            */
+#define NGP_MAX_PARAMS 96  /* continuous parameters per kernel tree            */
+#define NGP_MAX_STACK  16  /* RPN evaluation stack depth                       */
+#define NGP_MAX_AUX    192 /* appended + forecast rows per item (d_tail+d+m+1) */
+
+/* Formula variants.  AutoGP.jl's source is not available in the build
+ * container, so the per-node formulas are restated from memory (SURVEY.md
+ * Appendix B); each doubtful choice is a data-driven flag so that correcting
+ * it is a one-line spec change + fixture regeneration, not a kernel rewrite. */
+typedef struct ngp_spec {
+    int32_t se_form;       /* 0: a*exp(-0.5*d^2/l^2)       1: a*exp(-0.5*d^2/l)        */
+    int32_t periodic_form; /* 0: a*exp(-(2/l^2)*sin^2(pi*d/p))  1: a*exp(-(2/l)*sin^2(pi*d/p)) */
+    int32_t cp_form;       /* 0: sigma(x)=.5*(1+tanh((loc-x)/scale))  1: tanh((x-loc)/scale) */
+    int32_t reserved;
+    double  jitter;        /* added to the diagonal next to the noise variance */
+} ngp_spec;
+
+/* One particle's covariance kernel: the tree in postfix (RPN) order
+ * (left subtree, right subtree, operator); params are consumed in RPN order. */
+typedef struct ngp_kernel {
+    int32_t        n_ops;
+    int32_t        n_params;
+    const int32_t *ops;     /* [n_ops] opcodes 1..8                            */
+    const double  *params;  /* [n_params]                                      */
+    double         noise;   /* observation-noise variance on the diagonal      */
+} ngp_kernel;
+
+typedef int32_t ngp_status;
+enum {
+    NGP_OK               =  0,
+    NGP_ERR_ARG          = -1, /* null pointer / negative size                 */
+    NGP_ERR_PROGRAM      = -2, /* malformed kernel program                     */
+    NGP_ERR_TOO_LARGE    = -3, /* exceeds NGP_MAX_* or device memory           */
+    NGP_ERR_NO_DEVICE    = -4, /* no HIP device / extension not usable         */
+    NGP_ERR_STATE        = -5  /* job used out of order                        */
+};
+
+typedef struct ngp_ctx ngp_ctx;
+typedef struct ngp_job ngp_job;
+
+/* ---- context ------------------------------------------------------------- */
+ngp_status  ngp_ctx_create(int32_t device, ngp_ctx **out);
+void        ngp_ctx_destroy(ngp_ctx *ctx);
+ngp_status  ngp_set_spec(ngp_ctx *ctx, const ngp_spec *spec);
+ngp_status  ngp_get_spec(const ngp_ctx *ctx, ngp_spec *spec);
+void        ngp_default_spec(ngp_spec *spec);
+const char *ngp_strerror(ngp_status st);
+const char *ngp_version(void);
+/* validates a kernel program (arity, stack depth, parameter count) */
+ngp_status  ngp_kernel_check(const ngp_kernel *k);
+
+/* ---- covariance assembly (diagnostic / small blocks) ---------------------
+ * out[b] (n1 x n2, row-major) = k_b(t1_i, t2_j) (+ (noise_b + jitter) on the
+ * diagonal i==j when add_diag != 0).  Replaces AutoGP's covariance-matrix
+ * builder used under fit_smc!/predict_mvn (src/make_and_fit_model.jl:111,
+ * src/forecasting.jl:159).                                                   */
+ngp_status ngp_cov_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
+                         int32_t n1, const double *t1, int32_t n2, const double *t2,
+                         int32_t add_diag, double *out);
+
+/* ---- log marginal likelihood --------------------------------------------
+ * logml[b] = log N(y_b | 0, K_b(t,t) + (noise_b + jitter) I), b = 0..B-1.
+ * y is [B x n] with row stride ldy (ldy == 0: one y shared by all items).
+ * This is the per-particle evaluation inside fit_smc! / add_data! /
+ * mcmc_structure! (src/make_and_fit_model.jl:111, src/forecasting.jl:248,259). */
+ngp_status ngp_logml_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
+                           int32_t n, const double *t, const double *y, int64_t ldy,
+                           double *logml, int32_t *info);
+
+/* ---- posterior predictive ------------------------------------------------
+ * Per item: mu[b] (m), sigma[b] (m x m) of  f(t_new) | y_b  (+ observation
+ * noise on the new points when noise_on_new != 0), and logml[b] (may be NULL).
+ * Replaces the per-particle conditional MVN inside AutoGP.predict_mvn
+ * (src/forecasting.jl:159,179).                                              */
+ngp_status ngp_predict_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
+                             int32_t n, const double *t, const double *y, int64_t ldy,
+                             int32_t m, const double *t_new, int32_t noise_on_new,
+                             double *mu, double *sigma, double *logml, int32_t *info);
+
+/* ---- nowcast fan-out ------------------------------------------------------
+ * The whole body of forecast_with_nowcasts' per-scenario task for the default
+ * n_mcmc = n_hmc = 0 path (src/forecasting.jl:246-268), for P particles and D
+ * scenarios at once.  All scenarios share the appended dates
+ * (src/create_nowcast_data.jl:36-37), and K does not depend on y, so each
+ * particle is factorised ONCE; per scenario only the d appended observations
+ * differ.
+ *   in : P kernels; base data (t[n], y[n]); appended times t_add[d];
+ *        y_add [D x d] row-major; forecast times t_new[m].
+ *   out: logml_base[P]      log p(y | particle)                 (n points)
+ *        logml_full[P x D]  log p(y, y_add_s | particle)        (n+d points)
+ *                           -> add_data! incremental weight = full - base
+ *        mu   [P x D x m]   predictive mean given (y, y_add_s)
+ *        sigma[P x m x m]   predictive covariance (scenario-independent)
+ *        info [P]
+ * Any output pointer may be NULL.                                            */
+ngp_status ngp_nowcast_batch(ngp_ctx *ctx, int32_t P, const ngp_kernel *kernels,
+                             int32_t n, const double *t, const double *y,
+                             int32_t d, const double *t_add,
+                             int32_t D, const double *y_add,
+                             int32_t m, const double *t_new, int32_t noise_on_new,
+                             double *logml_base, double *logml_full,
+                             double *mu, double *sigma, int32_t *info);
+
+/* ---- gradient of the log marginal likelihood ------------------------------
+ * grad[b] has n_params_b + 1 entries: d logml / d params (RPN order) followed
+ * by d logml / d noise; items are packed back to back (offsets = running sum of
+ * n_params_b + 1).  Needed by the HMC moves of mcmc_parameters! / fit_smc!
+ * (src/forecasting.jl:178,261; src/make_and_fit_model.jl:111).               */
+ngp_status ngp_logml_grad_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
+                                int32_t n, const double *t, const double *y, int64_t ldy,
+                                double *logml, double *grad, int32_t *info);
+
+/* ---- particle weights -----------------------------------------------------
+ * maybe_resample! arithmetic (src/forecasting.jl:251-254): normalise P
+ * log-weights (logsumexp), effective sample size 1 / sum w^2.  In a multi-GPU
+ * run the caller all-gathers the per-rank log-weights first (the only
+ * collective on the path) and passes the gathered vector.
+ * w_norm (P, may be NULL), ess, log_norm (log sum exp logw) out.              */
+ngp_status ngp_weights_normalize(int32_t P, const double *logw,
+                                 double *w_norm, double *ess, double *log_norm);
+
+/* ---- staged execution (inputs resident in HBM before the timed region) ----
+ * stage  : validate, allocate device buffers, copy inputs host -> device
+ * run    : enqueue every kernel of the job and wait for completion
+ * fetch  : copy outputs device -> host (same output arguments as the one-shot
+ *          entry point that created the job; NULL pointers are skipped)
+ * The one-shot entry points above are stage + run + fetch + destroy.          */
+ngp_status ngp_logml_stage(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
+                           int32_t n, const double *t, const double *y, int64_t ldy,
+                           ngp_job **job);
+ngp_status ngp_predict_stage(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
+                             int32_t n, const double *t, const double *y, int64_t ldy,
+                             int32_t m, const double *t_new, int32_t noise_on_new,
+                             ngp_job **job);
+ngp_status ngp_nowcast_stage(ngp_ctx *ctx, int32_t P, const ngp_kernel *kernels,
+                             int32_t n, const double *t, const double *y,
+                             int32_t d, const double *t_add,
+                             int32_t D, const double *y_add,
+                             int32_t m, const double *t_new, int32_t noise_on_new,
+                             ngp_job **job);
+ngp_status ngp_job_run(ngp_job *job);
+ngp_status ngp_job_fetch(ngp_job *job, double *logml_base, double *logml_full,
+                         double *mu, double *sigma, int32_t *info);
+void       ngp_job_destroy(ngp_job *job);
+
+/* ---- measurement hooks -----------------------------------------------------
+ * HIP-event timing of the kernels a job launches, on the stream they are
+ * launched on.  Classes: 0 = chol_col (trailing-update GEMM + fused solve, the
+ * dominant kernel), 1 = chol_diag, 2 = gram, 3 = epilogue, 4 = cov fill,
+ * 5 = gradient kernels.                                                       */
+#define NGP_NUM_KERNEL_CLASSES 8
+typedef struct ngp_profile {
+    double   ms[NGP_NUM_KERNEL_CLASSES];       /* summed device time per class */
+    int64_t  launches[NGP_NUM_KERNEL_CLASSES]; /* kernel launches per class    */
+    double   flops[NGP_NUM_KERNEL_CLASSES];    /* algorithmic flops executed   */
+    double   bytes[NGP_NUM_KERNEL_CLASSES];    /* algorithmic HBM bytes        */
+} ngp_profile;
+ngp_status ngp_profile_enable(ngp_ctx *ctx, int32_t on);
+ngp_status ngp_profile_reset(ngp_ctx *ctx);
+ngp_status ngp_profile_get(ngp_ctx *ctx, ngp_profile *out);
+
+/* fp64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64); returns the
+ * measured dense TFLOP/s over `iters` back-to-back MFMAs per wave.            */
+ngp_status ngp_microbench_mfma_f64(ngp_ctx *ctx, int32_t iters, double *tflops);
+/* HBM streaming-write microbenchmark (GB/s) used to anchor the fill roofline. */
+ngp_status ngp_microbench_hbm(ngp_ctx *ctx, int64_t bytes, double *write_gbs, double *copy_gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGP_H */

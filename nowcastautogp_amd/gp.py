@@ -1,0 +1,292 @@
+"""Kernel grammar of the hot path: AutoGP.GP node types, ``GPConfig`` and the tree <-> program codec.
+
+Mirrors the names the reference re-exports and configures
+(``const GPConfig = AutoGP.GP.GPConfig``, reference src/NowcastAutoGP.jl:9; opcode numbering,
+``node_dist_*`` vectors, ``max_branch``/``max_depth``/``changepoints``/``noise`` and the
+``prior`` dict are the values printed at docs/src/vignettes/setting-priors.md:92-117,228-245).
+Prior *distributions* of the continuous parameters are recalled, not read (SURVEY.md Appendix
+B, [RECALLED]): each parameter is a deterministic transform of a N(0,1) latent.
+
+The device never sees these Python objects: ``to_program`` flattens a tree to the postfix
+``(ops, params)`` arrays that ``ngp_kernel`` (include/ngp.h) carries.
+"""
+from __future__ import annotations
+
+import copy
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+CONSTANT, LINEAR, SQUARED_EXPONENTIAL, GAMMA_EXPONENTIAL, PERIODIC, PLUS, TIMES, CHANGE_POINT = \
+    range(1, 9)
+
+# parameter names per opcode, in wire order (include/ngp.h)
+PARAM_NAMES = {
+    CONSTANT: ("value",),
+    LINEAR: ("intercept", "bias", "amplitude"),
+    SQUARED_EXPONENTIAL: ("lengthscale", "amplitude"),
+    GAMMA_EXPONENTIAL: ("lengthscale", "gamma", "amplitude"),
+    PERIODIC: ("lengthscale", "period", "amplitude"),
+    PLUS: (),
+    TIMES: (),
+    CHANGE_POINT: ("location", "scale"),
+}
+NODE_NAMES = {1: "Constant", 2: "Linear", 3: "SquaredExponential", 4: "GammaExponential",
+              5: "Periodic", 6: "Plus", 7: "Times", 8: "ChangePoint"}
+
+
+@dataclass
+class Node:
+    """A kernel-tree node; leaves have no children, operators have two."""
+    op: int
+    params: List[float] = field(default_factory=list)
+    left: Optional["Node"] = None
+    right: Optional["Node"] = None
+
+    @property
+    def is_leaf(self) -> bool:
+        return self.op < PLUS
+
+    def size(self) -> int:
+        return 1 if self.is_leaf else 1 + self.left.size() + self.right.size()
+
+    def depth(self) -> int:
+        return 1 if self.is_leaf else 1 + max(self.left.depth(), self.right.depth())
+
+    def __str__(self) -> str:
+        name = NODE_NAMES[self.op]
+        ps = ", ".join(f"{n}={v:.4g}" for n, v in zip(PARAM_NAMES[self.op], self.params))
+        if self.is_leaf:
+            return f"{name}({ps})"
+        inner = f"{self.left}, {self.right}"
+        return f"{name}({inner}{', ' + ps if ps else ''})"
+
+
+def Constant(value):
+    return Node(CONSTANT, [float(value)])
+
+
+def Linear(intercept, bias=1.0, amplitude=1.0):
+    return Node(LINEAR, [float(intercept), float(bias), float(amplitude)])
+
+
+def SquaredExponential(lengthscale, amplitude=1.0):
+    return Node(SQUARED_EXPONENTIAL, [float(lengthscale), float(amplitude)])
+
+
+def GammaExponential(lengthscale, gamma, amplitude=1.0):
+    return Node(GAMMA_EXPONENTIAL, [float(lengthscale), float(gamma), float(amplitude)])
+
+
+def Periodic(lengthscale, period, amplitude=1.0):
+    return Node(PERIODIC, [float(lengthscale), float(period), float(amplitude)])
+
+
+def Plus(left, right):
+    return Node(PLUS, [], left, right)
+
+
+def Times(left, right):
+    return Node(TIMES, [], left, right)
+
+
+def ChangePoint(left, right, location, scale):
+    return Node(CHANGE_POINT, [float(location), float(scale)], left, right)
+
+
+# ---------------------------------------------------------------------------
+# tree <-> postfix program
+# ---------------------------------------------------------------------------
+def to_program(node: Node) -> Tuple[np.ndarray, np.ndarray]:
+    """Flatten to postfix (left, right, operator); params in the same order."""
+    ops: List[int] = []
+    params: List[float] = []
+
+    def walk(nd: Node):
+        if not nd.is_leaf:
+            walk(nd.left)
+            walk(nd.right)
+        ops.append(nd.op)
+        params.extend(nd.params)
+
+    walk(node)
+    return np.asarray(ops, dtype=np.int32), np.asarray(params, dtype=np.float64)
+
+
+def from_program(ops: Sequence[int], params: Sequence[float]) -> Node:
+    stack: List[Node] = []
+    p = 0
+    params = [float(x) for x in params]
+    for op in ops:
+        op = int(op)
+        if op < 1 or op > 8:
+            raise ValueError(f"bad opcode {op}")
+        k = len(PARAM_NAMES[op])
+        if op < PLUS:
+            stack.append(Node(op, params[p:p + k]))
+        else:
+            if len(stack) < 2:
+                raise ValueError("malformed program: operator without two operands")
+            r, l = stack.pop(), stack.pop()
+            stack.append(Node(op, params[p:p + k], l, r))
+        p += k
+    if len(stack) != 1 or p != len(params):
+        raise ValueError("malformed program")
+    return stack[0]
+
+
+def stack_depth(ops: Sequence[int]) -> int:
+    d = mx = 0
+    for op in ops:
+        d += 1 if op < PLUS else -1
+        mx = max(mx, d)
+    return mx
+
+
+def set_params(node: Node, flat: Sequence[float]) -> Node:
+    """Return a copy of the tree with its parameters replaced (postfix order)."""
+    ops, _ = to_program(node)
+    return from_program(ops, flat)
+
+
+# ---------------------------------------------------------------------------
+# GPConfig (reference: docs/src/vignettes/setting-priors.md:228-245)
+# ---------------------------------------------------------------------------
+def _default_prior() -> Dict[str, Dict[str, float]]:
+    return {
+        "gamma": {"mu": 0.0, "sigma": 1.0},        # logit-normal scaled onto (0, 2)  [RECALLED]
+        "period": {"mu": -1.5, "sigma": 1.0},      # setting-priors.md:113-117
+        "wildcard": {"mu": -1.5, "sigma": 1.0},    # every other positive parameter [RECALLED]
+    }
+
+
+@dataclass
+class GPConfig:
+    Constant: int = CONSTANT
+    Linear: int = LINEAR
+    SquaredExponential: int = SQUARED_EXPONENTIAL
+    GammaExponential: int = GAMMA_EXPONENTIAL
+    Periodic: int = PERIODIC
+    Plus: int = PLUS
+    Times: int = TIMES
+    ChangePoint: int = CHANGE_POINT
+    node_dist_leaf: Sequence[float] = (0.0, 1 / 3, 0.0, 1 / 3, 1 / 3)
+    node_dist_nocp: Sequence[float] = (0.0, 3 / 14, 0.0, 3 / 14, 3 / 14, 5 / 28, 5 / 28)
+    node_dist_cp: Sequence[float] = (0.0, 3 / 14, 0.0, 3 / 14, 3 / 14, 1 / 7, 1 / 7, 1 / 14)
+    max_branch: int = 2
+    max_depth: int = -1
+    changepoints: bool = True
+    noise: Optional[float] = None
+    prior: Dict[str, Dict[str, float]] = field(default_factory=_default_prior)
+
+    def __post_init__(self):
+        for name, k in (("node_dist_leaf", 5), ("node_dist_nocp", 7), ("node_dist_cp", 8)):
+            v = np.asarray(getattr(self, name), dtype=np.float64)
+            if v.shape != (k,) or np.any(v < 0) or abs(v.sum() - 1.0) > 1e-9:
+                raise ValueError(f"{name} must be a probability vector of length {k}")
+            setattr(self, name, v)
+        if self.max_branch != 2:
+            raise ValueError("max_branch must be 2")
+
+
+# ---------------------------------------------------------------------------
+# latent <-> parameter transforms (HMC acts on the N(0,1) latents)  [RECALLED]
+# ---------------------------------------------------------------------------
+def _kind(op: int, name: str) -> str:
+    if name == "gamma":
+        return "gamma"
+    if name == "period":
+        return "period"
+    if op == LINEAR and name == "intercept":
+        return "real"
+    if op == CHANGE_POINT and name == "location":
+        return "unit"
+    return "wildcard"
+
+
+def param_kinds(ops: Sequence[int]) -> List[str]:
+    out: List[str] = []
+    for op in ops:
+        out.extend(_kind(int(op), nm) for nm in PARAM_NAMES[int(op)])
+    return out
+
+
+def transform(z: np.ndarray, kinds: Sequence[str], prior) -> Tuple[np.ndarray, np.ndarray]:
+    """latents z -> parameters theta and d theta / d z (elementwise)."""
+    z = np.asarray(z, dtype=np.float64)
+    th = np.empty_like(z)
+    dth = np.empty_like(z)
+    for i, kd in enumerate(kinds):
+        if kd == "real":
+            th[i], dth[i] = z[i], 1.0
+        elif kd == "unit":
+            s = 1.0 / (1.0 + math.exp(-z[i]))
+            th[i], dth[i] = s, s * (1 - s)
+        elif kd == "gamma":
+            pr = prior["gamma"]
+            s = 1.0 / (1.0 + math.exp(-(pr["mu"] + pr["sigma"] * z[i])))
+            th[i], dth[i] = 2.0 * s, 2.0 * s * (1 - s) * pr["sigma"]
+        else:
+            pr = prior["period"] if kd == "period" else prior["wildcard"]
+            v = math.exp(pr["mu"] + pr["sigma"] * z[i])
+            th[i], dth[i] = v, v * pr["sigma"]
+    return th, dth
+
+
+def untransform(theta: np.ndarray, kinds: Sequence[str], prior) -> np.ndarray:
+    theta = np.asarray(theta, dtype=np.float64)
+    z = np.empty_like(theta)
+    for i, kd in enumerate(kinds):
+        if kd == "real":
+            z[i] = theta[i]
+        elif kd == "unit":
+            z[i] = math.log(theta[i] / (1 - theta[i]))
+        elif kd == "gamma":
+            pr = prior["gamma"]
+            s = theta[i] / 2.0
+            z[i] = (math.log(s / (1 - s)) - pr["mu"]) / pr["sigma"]
+        else:
+            pr = prior["period"] if kd == "period" else prior["wildcard"]
+            z[i] = (math.log(theta[i]) - pr["mu"]) / pr["sigma"]
+    return z
+
+
+NOISE_KIND = "wildcard"
+
+
+# ---------------------------------------------------------------------------
+# prior over trees
+# ---------------------------------------------------------------------------
+def sample_tree(rng: np.random.Generator, config: GPConfig, depth: int = 1,
+                depth_cap: Optional[int] = None) -> Node:
+    """Draw a kernel tree from the grammar prior (params from their priors)."""
+    cap = config.max_depth if config.max_depth > 0 else depth_cap
+    if cap is not None and depth >= cap:
+        dist = config.node_dist_leaf
+    elif config.changepoints:
+        dist = config.node_dist_cp
+    else:
+        dist = config.node_dist_nocp
+    op = int(rng.choice(len(dist), p=np.asarray(dist))) + 1
+    if op < PLUS:
+        kinds = [_kind(op, nm) for nm in PARAM_NAMES[op]]
+        th, _ = transform(rng.standard_normal(len(kinds)), kinds, config.prior)
+        return Node(op, list(th))
+    left = sample_tree(rng, config, depth + 1, depth_cap)
+    right = sample_tree(rng, config, depth + 1, depth_cap)
+    kinds = [_kind(op, nm) for nm in PARAM_NAMES[op]]
+    th, _ = transform(rng.standard_normal(len(kinds)), kinds, config.prior)
+    return Node(op, list(th), left, right)
+
+
+def sample_noise(rng: np.random.Generator, config: GPConfig) -> float:
+    if config.noise is not None:
+        return float(config.noise)
+    th, _ = transform(rng.standard_normal(1), [NOISE_KIND], config.prior)
+    return float(th[0])
+
+
+def clone(node: Node) -> Node:
+    return copy.deepcopy(node)

@@ -1,0 +1,193 @@
+"""Second, independently written CPU oracle: numpy (vectorised tree evaluation) + scipy/LAPACK.
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+PARITY UNPINNED: AutoGP.jl (reference Project.toml:7,15), which holds this arithmetic, is not
+available here and the reference's tests pin no numeric GP output; this module restates the
+textbook identities and the recalled kernel grammar a second time,
+sharing no code with ``ngp_oracle.c``, so that the two agreeing (<= 1e-12 rel on the committed
+fixtures, tests/test_oracle.py) is the parity anchor available.
+
+It is also the CPU baseline of ``bench.py``: the same LAPACK family Julia's LinearAlgebra uses
+(OpenBLAS ``dpotrf``/``dpotrs``), run the way the reference runs it — BLAS threads = 1
+(src/forecasting.jl:114-123) and one worker thread per host core over (particle, scenario)
+items (src/forecasting.jl:244-245).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+from scipy.linalg import cho_solve, cholesky, solve_triangular
+
+LEAF_PARAMS = {1: 1, 2: 3, 3: 2, 4: 3, 5: 3}
+
+DEFAULT_SPEC = dict(se_form=0, periodic_form=0, cp_form=0, jitter=1e-5)
+
+
+def _spec(spec):
+    if spec is None:
+        return DEFAULT_SPEC
+    if isinstance(spec, dict):
+        return {**DEFAULT_SPEC, **spec}
+    return dict(se_form=spec.se_form, periodic_form=spec.periodic_form, cp_form=spec.cp_form,
+                jitter=spec.jitter)
+
+
+def rpn_to_tree(ops, params):
+    """postfix program -> nested tuples (op, params, left, right)."""
+    stack, p = [], 0
+    params = [float(x) for x in params]
+    for op in ops:
+        op = int(op)
+        if op in LEAF_PARAMS:
+            k = LEAF_PARAMS[op]
+            stack.append((op, tuple(params[p:p + k]), None, None))
+            p += k
+        elif op in (6, 7):
+            r, l = stack.pop(), stack.pop()
+            stack.append((op, (), l, r))
+        elif op == 8:
+            r, l = stack.pop(), stack.pop()
+            stack.append((op, tuple(params[p:p + 2]), l, r))
+            p += 2
+        else:
+            raise ValueError(f"bad opcode {op}")
+    if len(stack) != 1 or p != len(params):
+        raise ValueError("malformed program")
+    return stack[0]
+
+
+def _eval(node, T1, T2, sp):
+    op, pr, l, r = node
+    if op == 1:
+        return np.full(np.broadcast(T1, T2).shape, pr[0])
+    if op == 2:
+        c, bias, amp = pr
+        return bias + amp * (T1 - c) * (T2 - c)
+    if op == 3:
+        ls, amp = pr
+        den = ls if sp["se_form"] else ls * ls
+        return amp * np.exp(-0.5 * (T1 - T2) ** 2 / den)
+    if op == 4:
+        ls, gam, amp = pr
+        return amp * np.exp(-np.power(np.abs(T1 - T2) / ls, gam))
+    if op == 5:
+        ls, per, amp = pr
+        c = 2.0 / ls if sp["periodic_form"] else 2.0 / (ls * ls)
+        return amp * np.exp(-c * np.sin(np.pi * np.abs(T1 - T2) / per) ** 2)
+    if op == 6:
+        return _eval(l, T1, T2, sp) + _eval(r, T1, T2, sp)
+    if op == 7:
+        return _eval(l, T1, T2, sp) * _eval(r, T1, T2, sp)
+    if op == 8:
+        loc, sc = pr
+        if sp["cp_form"]:
+            s1, s2 = 0.5 * (1 + np.tanh((T1 - loc) / sc)), 0.5 * (1 + np.tanh((T2 - loc) / sc))
+        else:
+            s1, s2 = 0.5 * (1 + np.tanh((loc - T1) / sc)), 0.5 * (1 + np.tanh((loc - T2) / sc))
+        return s1 * _eval(l, T1, T2, sp) * s2 + (1 - s1) * _eval(r, T1, T2, sp) * (1 - s2)
+    raise ValueError(op)
+
+
+def cov(program, t1, t2, add_diag=False, spec=None):
+    ops, params, noise = program
+    sp = _spec(spec)
+    t1 = np.asarray(t1, dtype=np.float64)
+    t2 = np.asarray(t2, dtype=np.float64)
+    K = _eval(rpn_to_tree(ops, params), t1[:, None], t2[None, :], sp)
+    K = np.array(K, dtype=np.float64)
+    if add_diag:
+        k = min(K.shape)
+        K[np.arange(k), np.arange(k)] += noise + sp["jitter"]
+    return K
+
+
+def _factor(program, t, spec):
+    K = cov(program, t, t, True, spec)
+    try:
+        return cholesky(K, lower=True, check_finite=False), 0
+    except np.linalg.LinAlgError as e:  # "k-th leading minor ..."
+        msg = str(e)
+        k = int(msg.split("-th")[0].split()[-1]) if "-th" in msg else 1
+        return None, k
+
+
+def logml(program, t, y, spec=None):
+    t = np.asarray(t, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    L, info = _factor(program, t, spec)
+    if info:
+        return float("nan"), info
+    z = solve_triangular(L, y, lower=True, check_finite=False)
+    n = t.size
+    return float(-0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * n * math.log(2 * math.pi)), 0
+
+
+def predict(program, t, y, t_new, noise_on_new=True, spec=None):
+    sp = _spec(spec)
+    t = np.asarray(t, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    t_new = np.asarray(t_new, dtype=np.float64)
+    m = t_new.size
+    L, info = _factor(program, t, spec)
+    if info:
+        return np.full(m, np.nan), np.full((m, m), np.nan), float("nan"), info
+    z = solve_triangular(L, y, lower=True, check_finite=False)
+    lm = float(-0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * t.size * math.log(2 * math.pi))
+    K21 = cov(program, t_new, t, False, spec)
+    K22 = cov(program, t_new, t_new, False, spec)
+    alpha = cho_solve((L, True), y, check_finite=False)
+    mu = K21 @ alpha
+    sigma = K22 - K21 @ cho_solve((L, True), K21.T, check_finite=False)
+    sigma = 0.5 * (sigma + sigma.T)
+    if noise_on_new:
+        sigma[np.arange(m), np.arange(m)] += program[2] + sp["jitter"]
+    return mu, sigma, lm, 0
+
+
+def nowcast(program, t, y, t_add, y_add, t_new, noise_on_new=True, spec=None):
+    """One scenario at a time, full refactorisation at n+d (what the reference does)."""
+    t = np.asarray(t, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    t_add = np.asarray(t_add, dtype=np.float64)
+    y_add = np.asarray(y_add, dtype=np.float64).reshape(-1, t_add.size)
+    lb, info = logml(program, t, y, spec)
+    tt = np.concatenate([t, t_add])
+    lf, mus, sigma = [], [], None
+    for s in range(y_add.shape[0]):
+        yy = np.concatenate([y, y_add[s]])
+        mu, sg, l1, i1 = predict(program, tt, yy, t_new, noise_on_new, spec)
+        info = info or i1
+        lf.append(l1)
+        mus.append(mu)
+        if sigma is None:
+            sigma = sg
+    return lb, np.array(lf), np.array(mus), sigma, info
+
+
+def logml_grad_fd(program, t, y, spec=None, rel=1e-6):
+    """Central finite differences of this module's own logml (pins the analytic gradient)."""
+    ops, params, noise = program
+    params = np.asarray(params, dtype=np.float64)
+    g = np.empty(params.size + 1)
+    for j in range(params.size + 1):
+        def f(delta):
+            p = params.copy()
+            nz = noise
+            if j < params.size:
+                p[j] += delta
+            else:
+                nz += delta
+            return logml((ops, p, nz), t, y, spec)[0]
+        base = abs(params[j]) if j < params.size else abs(noise)
+        h = rel * max(base, 1e-3)
+        g[j] = (f(h) - f(-h)) / (2 * h)
+    return g
+
+
+def weights_normalize(logw):
+    logw = np.asarray(logw, dtype=np.float64)
+    mx = logw.max()
+    e = np.exp(logw - mx)
+    w = e / e.sum()
+    return w, float(1.0 / np.sum(w * w)), float(mx + math.log(e.sum()))
