@@ -217,6 +217,9 @@ ngp_status ngp_profile_get(ngp_ctx *ctx, ngp_profile *out);
 /* fp64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64); returns the
  * measured dense TFLOP/s over `iters` back-to-back MFMAs per wave.            */
 ngp_status ngp_microbench_mfma_f64(ngp_ctx *ctx, int32_t iters, double *tflops);
+/* One v_mfma_f64_16x16x4_f64 through the operand maps the kernels assume:
+ * D[16x16] = A[16x4] B[4x16], all row-major; the caller compares with A @ B.   */
+ngp_status ngp_selftest_mfma_layout(ngp_ctx *ctx, const double *A, const double *B, double *D);
 /* HBM streaming-write microbenchmark (GB/s) used to anchor the fill roofline. */
 ngp_status ngp_microbench_hbm(ngp_ctx *ctx, int64_t bytes, double *write_gbs, double *copy_gbs);
 

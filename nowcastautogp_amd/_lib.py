@@ -1,0 +1,342 @@
+"""ctypes binding of ``libngp.so`` (C-ABI: ``include/ngp.h``) — the ONLY compute path.
+
+There is no CPU fallback: if the HIP library is missing or no device is usable the calls
+raise ``NgpError`` / ``RuntimeError`` loudly.  Build with ``python -c "import __graft_entry__ as
+g; g.build()"`` (hipcc --offload-arch=gfx950).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from ._abi import (KernelArray, NgpKernel, NgpProfile, NgpSpec, as_f64, c_double_p, c_int32_p,
+                   dptr, iptr)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libngp.so")
+
+KERNEL_CLASSES = ("chol_col", "chol_diag", "gram", "epilogue", "fill", "grad", "r6", "r7")
+
+# every symbol include/ngp.h declares (tests/test_abi.py checks the library exports them all)
+SYMBOLS = (
+    "ngp_ctx_create", "ngp_ctx_destroy", "ngp_set_spec", "ngp_get_spec", "ngp_default_spec",
+    "ngp_strerror", "ngp_version", "ngp_kernel_check", "ngp_cov_batch", "ngp_logml_batch",
+    "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
+    "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
+    "ngp_job_destroy", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
+    "ngp_microbench_mfma_f64", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
+)
+
+
+class NgpError(RuntimeError):
+    def __init__(self, status: int, where: str):
+        self.status = status
+        super().__init__(f"{where}: {_strerror(status)} (status {status})")
+
+
+class PosDefException(ArithmeticError):
+    """Leading minor ``k`` of a covariance matrix is not positive definite (LAPACK potrf info;
+    the reference surfaces this as Julia's PosDefException, src/make_and_fit_model.jl:26-28)."""
+
+    def __init__(self, k: int, item: int):
+        self.info, self.item = k, item
+        super().__init__(f"matrix is not positive definite; Cholesky failed at minor {k} "
+                         f"(item {item})")
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run __graft_entry__.build()); there is no CPU fallback for the GP hot path")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f64p, i32p = C.c_void_p, C.c_int32, C.c_int64, c_double_p, c_int32_p
+    KP, SP = C.POINTER(NgpKernel), C.POINTER(NgpSpec)
+    sig = {
+        "ngp_ctx_create": (i32, [i32, C.POINTER(vp)]),
+        "ngp_ctx_destroy": (None, [vp]),
+        "ngp_set_spec": (i32, [vp, SP]),
+        "ngp_get_spec": (i32, [vp, SP]),
+        "ngp_default_spec": (None, [SP]),
+        "ngp_strerror": (C.c_char_p, [i32]),
+        "ngp_version": (C.c_char_p, []),
+        "ngp_kernel_check": (i32, [KP]),
+        "ngp_cov_batch": (i32, [vp, i32, KP, i32, f64p, i32, f64p, i32, f64p]),
+        "ngp_logml_batch": (i32, [vp, i32, KP, i32, f64p, f64p, i64, f64p, i32p]),
+        "ngp_predict_batch": (i32, [vp, i32, KP, i32, f64p, f64p, i64, i32, f64p, i32, f64p, f64p,
+                                    f64p, i32p]),
+        "ngp_nowcast_batch": (i32, [vp, i32, KP, i32, f64p, f64p, i32, f64p, i32, f64p, i32, f64p,
+                                    i32, f64p, f64p, f64p, f64p, i32p]),
+        "ngp_logml_grad_batch": (i32, [vp, i32, KP, i32, f64p, f64p, i64, f64p, f64p, i32p]),
+        "ngp_weights_normalize": (i32, [i32, f64p, f64p, f64p, f64p]),
+        "ngp_logml_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, C.POINTER(vp)]),
+        "ngp_predict_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, i32, f64p, i32,
+                                    C.POINTER(vp)]),
+        "ngp_nowcast_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i32, f64p, i32, f64p, i32, f64p,
+                                    i32, C.POINTER(vp)]),
+        "ngp_job_run": (i32, [vp]),
+        "ngp_job_fetch": (i32, [vp, f64p, f64p, f64p, f64p, i32p]),
+        "ngp_job_destroy": (None, [vp]),
+        "ngp_profile_enable": (i32, [vp, i32]),
+        "ngp_profile_reset": (i32, [vp]),
+        "ngp_profile_get": (i32, [vp, C.POINTER(NgpProfile)]),
+        "ngp_microbench_mfma_f64": (i32, [vp, i32, f64p]),
+        "ngp_microbench_hbm": (i32, [vp, i64, f64p, f64p]),
+        "ngp_selftest_mfma_layout": (i32, [vp, f64p, f64p, f64p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _strerror(st: int) -> str:
+    try:
+        return load().ngp_strerror(int(st)).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def _chk(st: int, where: str):
+    if st != 0:
+        raise NgpError(int(st), where)
+
+
+def kernel_check(program) -> int:
+    ka = KernelArray([program])
+    return int(load().ngp_kernel_check(C.byref(ka.arr[0])))
+
+
+def weights_normalize(logw):
+    """maybe_resample! arithmetic (reference src/forecasting.jl:251-254); host-side, P doubles."""
+    logw = as_f64(logw)
+    w = np.empty(logw.size)
+    ess, ln = C.c_double(), C.c_double()
+    _chk(load().ngp_weights_normalize(logw.size, dptr(logw), dptr(w), C.byref(ess), C.byref(ln)),
+         "ngp_weights_normalize")
+    return w, float(ess.value), float(ln.value)
+
+
+def _nullable(a: Optional[np.ndarray]):
+    return dptr(a) if a is not None else None
+
+
+class Job:
+    """A staged batch: inputs resident in HBM; ``run`` enqueues every kernel and waits."""
+
+    def __init__(self, ctx: "Context", handle, P: int, D: int, m: int, keep):
+        self.ctx, self._h, self.P, self.D, self.m = ctx, handle, P, D, m
+        self._keep = keep
+
+    def run(self):
+        _chk(load().ngp_job_run(self._h), "ngp_job_run")
+        return self
+
+    def fetch(self):
+        P, D, m = self.P, self.D, self.m
+        lb, lf = np.empty(P), np.empty((P, D))
+        mu = np.empty((P, D, m)) if m else None
+        sg = np.empty((P, m, m)) if m else None
+        info = np.zeros(P, dtype=np.int32)
+        _chk(load().ngp_job_fetch(self._h, dptr(lb), dptr(lf), _nullable(mu), _nullable(sg),
+                                  iptr(info)), "ngp_job_fetch")
+        return dict(logml_base=lb, logml_full=lf, mu=mu, sigma=sg, info=info)
+
+    def close(self):
+        if self._h is not None:
+            load().ngp_job_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context:
+    """One HIP device + stream (``ngp_ctx``).  Raises if no MI355X is usable."""
+
+    def __init__(self, device: int = 0, spec: Optional[NgpSpec] = None):
+        L = load()
+        h = C.c_void_p()
+        st = L.ngp_ctx_create(int(device), C.byref(h))
+        if st != 0:
+            raise NgpError(int(st), "ngp_ctx_create (the GP hot path has no CPU fallback)")
+        self._h = h
+        self.device = device
+        if spec is not None:
+            self.set_spec(spec)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            load().ngp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- spec ---------------------------------------------------------------------------
+    def set_spec(self, spec: NgpSpec):
+        _chk(load().ngp_set_spec(self._h, C.byref(spec)), "ngp_set_spec")
+
+    def get_spec(self) -> NgpSpec:
+        s = NgpSpec()
+        _chk(load().ngp_get_spec(self._h, C.byref(s)), "ngp_get_spec")
+        return s
+
+    # ---- one-shot entry points ---------------------------------------------------------
+    def cov_batch(self, programs: Sequence, t1, t2, add_diag=False):
+        ka = KernelArray(programs)
+        t1, t2 = as_f64(t1), as_f64(t2)
+        out = np.empty((ka.n, t1.size, t2.size))
+        _chk(load().ngp_cov_batch(self._h, ka.n, ka.arr, t1.size, dptr(t1), t2.size, dptr(t2),
+                                  int(add_diag), dptr(out)), "ngp_cov_batch")
+        return out
+
+    @staticmethod
+    def _ymat(y, B, n):
+        y = as_f64(y)
+        if y.ndim == 1:
+            if y.size != n:
+                raise ValueError("y has the wrong length")
+            return y, 0
+        if y.shape != (B, n):
+            raise ValueError("y must be [n] or [B, n]")
+        return y, n
+
+    def logml_batch(self, programs, t, y):
+        ka = KernelArray(programs)
+        t = as_f64(t)
+        y, ldy = self._ymat(y, ka.n, t.size)
+        out, info = np.empty(ka.n), np.zeros(ka.n, dtype=np.int32)
+        _chk(load().ngp_logml_batch(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy,
+                                    dptr(out), iptr(info)), "ngp_logml_batch")
+        return out, info
+
+    def predict_batch(self, programs, t, y, t_new, noise_on_new=True):
+        ka = KernelArray(programs)
+        t, t_new = as_f64(t), as_f64(t_new)
+        y, ldy = self._ymat(y, ka.n, t.size)
+        m = t_new.size
+        mu, sg = np.empty((ka.n, m)), np.empty((ka.n, m, m))
+        lm, info = np.empty(ka.n), np.zeros(ka.n, dtype=np.int32)
+        _chk(load().ngp_predict_batch(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy, m,
+                                      dptr(t_new), int(noise_on_new), dptr(mu), dptr(sg),
+                                      dptr(lm), iptr(info)), "ngp_predict_batch")
+        return mu, sg, lm, info
+
+    def nowcast_batch(self, programs, t, y, t_add, y_add, t_new, noise_on_new=True):
+        ka = KernelArray(programs)
+        t, y, t_add, t_new = as_f64(t), as_f64(y), as_f64(t_add), as_f64(t_new)
+        d, m = t_add.size, t_new.size
+        y_add = as_f64(y_add).reshape(-1, d) if d else np.zeros((1, 0))
+        D = y_add.shape[0]
+        lb, lf = np.empty(ka.n), np.empty((ka.n, D))
+        mu = np.empty((ka.n, D, m)) if m else None
+        sg = np.empty((ka.n, m, m)) if m else None
+        info = np.zeros(ka.n, dtype=np.int32)
+        _chk(load().ngp_nowcast_batch(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), d,
+                                      dptr(t_add) if d else None, D,
+                                      dptr(y_add) if d else None, m,
+                                      dptr(t_new) if m else None, int(noise_on_new), dptr(lb),
+                                      dptr(lf), _nullable(mu), _nullable(sg), iptr(info)),
+             "ngp_nowcast_batch")
+        return dict(logml_base=lb, logml_full=lf, mu=mu, sigma=sg, info=info)
+
+    def logml_grad_batch(self, programs, t, y):
+        ka = KernelArray(programs)
+        t = as_f64(t)
+        y, ldy = self._ymat(y, ka.n, t.size)
+        sizes = [p + 1 for p in ka.n_params]
+        grad = np.empty(int(sum(sizes)))
+        lm, info = np.empty(ka.n), np.zeros(ka.n, dtype=np.int32)
+        _chk(load().ngp_logml_grad_batch(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy,
+                                         dptr(lm), dptr(grad), iptr(info)),
+             "ngp_logml_grad_batch")
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+        return lm, [grad[offs[i]:offs[i + 1]] for i in range(ka.n)], info
+
+    # ---- staged ---------------------------------------------------------------------------
+    def stage_logml(self, programs, t, y) -> Job:
+        ka = KernelArray(programs)
+        t = as_f64(t)
+        y, ldy = self._ymat(y, ka.n, t.size)
+        h = C.c_void_p()
+        _chk(load().ngp_logml_stage(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy,
+                                    C.byref(h)), "ngp_logml_stage")
+        return Job(self, h, ka.n, 1, 0, (ka, t, y))
+
+    def stage_predict(self, programs, t, y, t_new, noise_on_new=True) -> Job:
+        ka = KernelArray(programs)
+        t, t_new = as_f64(t), as_f64(t_new)
+        y, ldy = self._ymat(y, ka.n, t.size)
+        h = C.c_void_p()
+        _chk(load().ngp_predict_stage(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy,
+                                      t_new.size, dptr(t_new), int(noise_on_new), C.byref(h)),
+             "ngp_predict_stage")
+        return Job(self, h, ka.n, 1, t_new.size, (ka, t, y, t_new))
+
+    def stage_nowcast(self, programs, t, y, t_add, y_add, t_new, noise_on_new=True) -> Job:
+        ka = KernelArray(programs)
+        t, y, t_add, t_new = as_f64(t), as_f64(y), as_f64(t_add), as_f64(t_new)
+        d, m = t_add.size, t_new.size
+        y_add = as_f64(y_add).reshape(-1, d)
+        D = y_add.shape[0]
+        h = C.c_void_p()
+        _chk(load().ngp_nowcast_stage(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), d,
+                                      dptr(t_add), D, dptr(y_add), m,
+                                      dptr(t_new) if m else None, int(noise_on_new), C.byref(h)),
+             "ngp_nowcast_stage")
+        return Job(self, h, ka.n, D, m, (ka, t, y, t_add, y_add, t_new))
+
+    # ---- measurement ----------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _chk(load().ngp_profile_enable(self._h, int(bool(on))), "ngp_profile_enable")
+
+    def profile_reset(self):
+        _chk(load().ngp_profile_reset(self._h), "ngp_profile_reset")
+
+    def profile_get(self) -> dict:
+        p = NgpProfile()
+        _chk(load().ngp_profile_get(self._h, C.byref(p)), "ngp_profile_get")
+        return {name: dict(ms=p.ms[i], launches=int(p.launches[i]), flops=p.flops[i],
+                           bytes=p.bytes[i])
+                for i, name in enumerate(KERNEL_CLASSES) if p.launches[i]}
+
+    def microbench_mfma_f64(self, iters=20000) -> float:
+        v = C.c_double()
+        _chk(load().ngp_microbench_mfma_f64(self._h, iters, C.byref(v)), "ngp_microbench_mfma_f64")
+        return float(v.value)
+
+    def microbench_hbm(self, nbytes=1 << 30):
+        w, c = C.c_double(), C.c_double()
+        _chk(load().ngp_microbench_hbm(self._h, nbytes, C.byref(w), C.byref(c)),
+             "ngp_microbench_hbm")
+        return float(w.value), float(c.value)
+
+    def selftest_mfma_layout(self, A, B):
+        A, B = as_f64(A).reshape(16, 4), as_f64(B).reshape(4, 16)
+        D = np.empty((16, 16))
+        _chk(load().ngp_selftest_mfma_layout(self._h, dptr(A), dptr(B), dptr(D)),
+             "ngp_selftest_mfma_layout")
+        return D
+
+
+def raise_if_not_posdef(info: np.ndarray):
+    bad = np.flatnonzero(np.asarray(info) != 0)
+    if bad.size:
+        raise PosDefException(int(info[bad[0]]), int(bad[0]))

@@ -1,0 +1,763 @@
+// ngp_api.hip — host side of libngp: contexts, staged jobs, launch schedule, C-ABI (include/ngp.h).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "ngp_internal.h"
+
+using namespace ngp;
+
+#define HIPCHK(expr)                                                     \
+    do {                                                                 \
+        hipError_t e__ = (expr);                                         \
+        if (e__ != hipSuccess) return (ngp_status)(e__ > 0 ? e__ : 999); \
+    } while (0)
+
+namespace {
+
+constexpr int k_nparams[10] = {0, 1, 3, 2, 3, 3, 0, 0, 2, 2};
+
+// ---------------------------------------------------------------------------------------
+// program validation + flattening for the device
+// ---------------------------------------------------------------------------------------
+ngp_status check_program(const ngp_kernel *k) {
+    if (!k || !k->ops || k->n_ops <= 0) return NGP_ERR_PROGRAM;
+    if (k->n_ops > NGP_MAX_OPS) return NGP_ERR_TOO_LARGE;
+    int depth = 0, np = 0;
+    for (int i = 0; i < k->n_ops; ++i) {
+        const int op = k->ops[i];
+        if (op < 1 || op > 8) return NGP_ERR_PROGRAM;
+        np += k_nparams[op];
+        if (op >= NGP_OP_PLUS) {
+            if (depth < 2) return NGP_ERR_PROGRAM;
+            depth -= 1;
+        } else {
+            depth += 1;
+            if (depth > NGP_MAX_STACK) return NGP_ERR_TOO_LARGE;
+        }
+    }
+    if (depth != 1) return NGP_ERR_PROGRAM;
+    if (np != k->n_params) return NGP_ERR_PROGRAM;
+    if (np > NGP_MAX_PARAMS) return NGP_ERR_TOO_LARGE;
+    if (np > 0 && !k->params) return NGP_ERR_PROGRAM;
+    return NGP_OK;
+}
+
+struct TNode {
+    int op, left, right, pfirst, need;
+};
+
+// Re-emit the postfix program so the deeper subtree of every operator is evaluated first
+// (Sethi-Ullman): the device keeps its evaluation stack in DEV_STACK registers.  Plus/Times
+// commute bit-exactly in IEEE arithmetic; ChangePoint gets a swapped-operand opcode.
+// perm[device param index] = caller's param index.
+ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int> *perm) {
+    ngp_status st = check_program(k);
+    if (st) return st;
+    std::vector<TNode> nodes;
+    std::vector<int> stack;
+    int pi = 0;
+    for (int i = 0; i < k->n_ops; ++i) {
+        const int op = k->ops[i];
+        TNode nd{op, -1, -1, pi, 1};
+        if (op >= NGP_OP_PLUS) {
+            nd.right = stack.back(); stack.pop_back();
+            nd.left = stack.back(); stack.pop_back();
+            const int a = nodes[nd.left].need, b = nodes[nd.right].need;
+            nd.need = (a == b) ? a + 1 : std::max(a, b);
+        }
+        pi += k_nparams[op];
+        nodes.push_back(nd);
+        stack.push_back((int)nodes.size() - 1);
+    }
+    if (nodes[stack.back()].need > DEV_STACK) return NGP_ERR_TOO_LARGE;
+    std::memset(out, 0, sizeof(DevProgram));
+    out->n_ops = k->n_ops;
+    out->n_params = k->n_params;
+    out->noise = k->noise;
+    int no = 0, np = 0;
+    if (perm) perm->clear();
+    // iterative post-order with child reordering
+    struct Frame { int node, stage; };
+    std::vector<Frame> fs{{stack.back(), 0}};
+    while (!fs.empty()) {
+        Frame &f = fs.back();
+        const TNode &nd = nodes[f.node];
+        const bool swap = nd.op >= NGP_OP_PLUS && nodes[nd.right].need > nodes[nd.left].need;
+        if (nd.op < NGP_OP_PLUS || f.stage == 2) {
+            int op = nd.op;
+            if (op == NGP_OP_CHANGEPOINT && swap) op = OP_CP_SWAPPED;
+            out->ops[no++] = (uint8_t)op;
+            for (int q = 0; q < k_nparams[nd.op]; ++q) {
+                out->params[np++] = k->params[nd.pfirst + q];
+                if (perm) perm->push_back(nd.pfirst + q);
+            }
+            fs.pop_back();
+        } else if (f.stage == 0) {
+            f.stage = 1;
+            fs.push_back({swap ? nd.right : nd.left, 0});
+        } else {
+            f.stage = 2;
+            fs.push_back({swap ? nd.left : nd.right, 0});
+        }
+    }
+    return NGP_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+struct ngp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ngp_spec spec{};
+    std::mutex mu;
+    bool profiling = false;
+    ngp_profile prof{};
+    size_t mem_cap = 0;  // bytes the factor storage of one job may take
+    // caching allocator: repeated jobs of the same shape (the SMC/MCMC loop) reuse blocks
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live;
+
+    ngp_status alloc(void **p, size_t bytes) {
+        bytes = (bytes + 255) / 256 * 256;
+        if (bytes == 0) bytes = 256;
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= bytes * 2) {
+            *p = it->second;
+            live[*p] = it->first;
+            free_blocks.erase(it);
+            return NGP_OK;
+        }
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) {  // drop the cache and retry once
+            for (auto &kv : free_blocks) (void)hipFree(kv.second);
+            free_blocks.clear();
+            e = hipMalloc(p, bytes);
+            if (e != hipSuccess) return NGP_ERR_TOO_LARGE;
+        }
+        live[*p] = bytes;
+        return NGP_OK;
+    }
+    void release(void *p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.emplace(it->second, p);
+        live.erase(it);
+    }
+};
+
+static DevSpec dev_spec(const ngp_spec &s) {
+    return DevSpec{s.se_form, s.periodic_form, s.cp_form, 0, s.jitter};
+}
+
+extern "C" void ngp_default_spec(ngp_spec *s) {
+    if (!s) return;
+    s->se_form = 0;
+    s->periodic_form = 0;
+    s->cp_form = 0;
+    s->reserved = 0;
+    s->jitter = 1e-5;
+}
+
+extern "C" const char *ngp_version(void) { return "libngp 0.1.0 (gfx950)"; }
+
+extern "C" const char *ngp_strerror(ngp_status st) {
+    switch (st) {
+    case NGP_OK: return "ok";
+    case NGP_ERR_ARG: return "bad argument (null pointer or negative size)";
+    case NGP_ERR_PROGRAM: return "malformed kernel program";
+    case NGP_ERR_TOO_LARGE: return "problem exceeds a library limit or device memory";
+    case NGP_ERR_NO_DEVICE: return "no usable HIP device";
+    case NGP_ERR_STATE: return "job used out of order / entry point unavailable";
+    default: break;
+    }
+    if (st > 0) return hipGetErrorString((hipError_t)st);
+    return "unknown error";
+}
+
+extern "C" ngp_status ngp_kernel_check(const ngp_kernel *k) {
+    DevProgram tmp;
+    return compile_program(k, &tmp, nullptr);
+}
+
+extern "C" ngp_status ngp_ctx_create(int32_t device, ngp_ctx **out) {
+    if (!out) return NGP_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NGP_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return NGP_ERR_ARG;
+    HIPCHK(hipSetDevice(device));
+    ngp_ctx *c = new (std::nothrow) ngp_ctx();
+    if (!c) return NGP_ERR_TOO_LARGE;
+    c->device = device;
+    ngp_default_spec(&c->spec);
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return (ngp_status)e;
+    }
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->mem_cap = (size_t)(0.6 * (double)fr);
+    else c->mem_cap = (size_t)8 << 30;
+    *out = c;
+    return NGP_OK;
+}
+
+extern "C" void ngp_ctx_destroy(ngp_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->free_blocks) (void)hipFree(kv.second);
+    for (auto &kv : c->live) (void)hipFree(kv.first);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" ngp_status ngp_set_spec(ngp_ctx *c, const ngp_spec *s) {
+    if (!c || !s) return NGP_ERR_ARG;
+    if (s->se_form < 0 || s->se_form > 1 || s->periodic_form < 0 || s->periodic_form > 1 ||
+        s->cp_form < 0 || s->cp_form > 1 || !(s->jitter >= 0.0))
+        return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->spec = *s;
+    return NGP_OK;
+}
+extern "C" ngp_status ngp_get_spec(const ngp_ctx *c, ngp_spec *s) {
+    if (!c || !s) return NGP_ERR_ARG;
+    *s = c->spec;
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_profile_enable(ngp_ctx *c, int32_t on) {
+    if (!c) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->profiling = on != 0;
+    return NGP_OK;
+}
+extern "C" ngp_status ngp_profile_reset(ngp_ctx *c) {
+    if (!c) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::memset(&c->prof, 0, sizeof(c->prof));
+    return NGP_OK;
+}
+extern "C" ngp_status ngp_profile_get(ngp_ctx *c, ngp_profile *out) {
+    if (!c || !out) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    *out = c->prof;
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// jobs
+// ---------------------------------------------------------------------------------------
+struct ngp_job {
+    ngp_ctx *ctx = nullptr;
+    JobGeom g{};
+    int n = 0;          // base training points (n0 + tail)
+    bool ran = false;
+    // device buffers
+    DevProgram *progs = nullptr;
+    double *t0 = nullptr, *taux = nullptr, *y0 = nullptr, *ya = nullptr;
+    double *logdet = nullptr, *G = nullptr, *work = nullptr, *zbuf = nullptr;
+    int32_t *info = nullptr;
+    double *logml_base = nullptr, *logml_full = nullptr, *mu = nullptr, *sigma = nullptr;
+    int64_t work_stride = 0;
+    std::vector<void *> owned;
+};
+
+namespace {
+
+struct EventTimer {  // HIP events on the launch stream, resolved after the job's final sync
+    struct Rec { int cls; hipEvent_t a, b; double flops, bytes; };
+    std::vector<Rec> recs;
+    bool on;
+    hipStream_t s;
+    EventTimer(bool on_, hipStream_t s_) : on(on_), s(s_) {}
+    template <class F> void run(int cls, double flops, double bytes, F &&f) {
+        if (!on) { f(); return; }
+        Rec r{cls, nullptr, nullptr, flops, bytes};
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, s);
+        f();
+        (void)hipEventRecord(r.b, s);
+        recs.push_back(r);
+    }
+    void resolve(ngp_profile &p) {
+        for (auto &r : recs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                p.ms[r.cls] += ms;
+                p.launches[r.cls] += 1;
+                p.flops[r.cls] += r.flops;
+                p.bytes[r.cls] += r.bytes;
+            }
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+        recs.clear();
+    }
+};
+
+template <class T> ngp_status job_alloc(ngp_job *j, T **p, size_t count) {
+    void *v = nullptr;
+    ngp_status st = j->ctx->alloc(&v, count * sizeof(T));
+    if (st) return st;
+    j->owned.push_back(v);
+    *p = (T *)v;
+    return NGP_OK;
+}
+
+// Stage a job in its general form: P kernels; base data (t[n], y [P or 1][n]); d appended
+// times; D scenarios y_add [(P or 1)][D][d]; m forecast times.
+ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, const double *t,
+                         const double *y, int64_t ldy, int d, const double *t_add, int D,
+                         const double *y_add, int64_t ld_yadd_item, int m, const double *t_new,
+                         int noise_on_new, ngp_job **out) {
+    if (!c || !out || !kernels || P <= 0 || n < 0 || d < 0 || m < 0 || D <= 0) return NGP_ERR_ARG;
+    if (n + d <= 0) return NGP_ERR_ARG;
+    if ((n > 0 && (!t || !y)) || (d > 0 && (!t_add || !y_add)) || (m > 0 && !t_new))
+        return NGP_ERR_ARG;
+    *out = nullptr;
+    std::vector<DevProgram> hp((size_t)P);
+    for (int i = 0; i < P; ++i) {
+        ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], nullptr);
+        if (st) return st;
+    }
+    JobGeom g{};
+    g.B = P;
+    g.n0 = (n / NB) * NB;
+    g.nb0 = g.n0 / NB;
+    g.tail = n - g.n0;
+    g.da = g.tail + d;
+    g.d = d;
+    g.m = m;
+    g.naux = g.da + m + 1;
+    if (g.naux > NGP_MAX_AUX) return NGP_ERR_TOO_LARGE;
+    g.naux_pad = (g.naux + NB - 1) / NB * NB;
+    g.D = D;
+    g.noise_on_new = noise_on_new ? 1 : 0;
+    g.y_shared = (ldy == 0) ? 1 : 0;
+    g.ld = g.n0;
+    g.item_stride = (int64_t)(g.n0 + g.naux_pad) * g.n0;
+
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    ngp_job *j = new (std::nothrow) ngp_job();
+    if (!j) return NGP_ERR_TOO_LARGE;
+    j->ctx = c;
+    j->g = g;
+    j->n = n;
+    ngp_status st = NGP_OK;
+    auto fail = [&](ngp_status s) {
+        for (void *p : j->owned) c->release(p);
+        delete j;
+        return s;
+    };
+    const int ny = g.y_shared ? 1 : P;
+    // host-side assembly of the small inputs
+    std::vector<double> h_taux((size_t)std::max(g.da + m, 1));
+    for (int a = 0; a < g.tail; ++a) h_taux[(size_t)a] = t[g.n0 + a];
+    for (int a = 0; a < d; ++a) h_taux[(size_t)(g.tail + a)] = t_add[a];
+    for (int i = 0; i < m; ++i) h_taux[(size_t)(g.da + i)] = t_new[i];
+    std::vector<double> h_y0((size_t)std::max(ny * g.n0, 1));
+    for (int b = 0; b < ny; ++b)
+        for (int i = 0; i < g.n0; ++i) h_y0[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
+    std::vector<double> h_ya((size_t)std::max((int64_t)ny * D * g.da, (int64_t)1));
+    for (int b = 0; b < ny; ++b)
+        for (int s = 0; s < D; ++s) {
+            double *dst = &h_ya[((size_t)b * D + s) * g.da];
+            for (int a = 0; a < g.tail; ++a) dst[a] = y[(int64_t)b * ldy + g.n0 + a];
+            for (int a = 0; a < d; ++a)
+                dst[g.tail + a] = y_add[(int64_t)b * ld_yadd_item + (int64_t)s * d + a];
+        }
+    if ((st = job_alloc(j, &j->progs, (size_t)P))) return fail(st);
+    if ((st = job_alloc(j, &j->t0, (size_t)std::max(g.n0, 1)))) return fail(st);
+    if ((st = job_alloc(j, &j->taux, h_taux.size()))) return fail(st);
+    if ((st = job_alloc(j, &j->y0, h_y0.size()))) return fail(st);
+    if ((st = job_alloc(j, &j->ya, h_ya.size()))) return fail(st);
+    if ((st = job_alloc(j, &j->logdet, (size_t)P))) return fail(st);
+    if ((st = job_alloc(j, &j->info, (size_t)P))) return fail(st);
+    if ((st = job_alloc(j, &j->G, (size_t)P * g.naux * g.naux))) return fail(st);
+    j->work_stride = (int64_t)g.da * g.da + (int64_t)m * g.da + g.da + 8;
+    if ((st = job_alloc(j, &j->work, (size_t)P * j->work_stride))) return fail(st);
+    if ((st = job_alloc(j, &j->zbuf, (size_t)std::max((int64_t)P * D * g.da, (int64_t)1))))
+        return fail(st);
+    if ((st = job_alloc(j, &j->logml_base, (size_t)P))) return fail(st);
+    if ((st = job_alloc(j, &j->logml_full, (size_t)P * D))) return fail(st);
+    if (m > 0) {
+        if ((st = job_alloc(j, &j->mu, (size_t)P * D * m))) return fail(st);
+        if ((st = job_alloc(j, &j->sigma, (size_t)P * m * m))) return fail(st);
+    }
+    hipStream_t s = c->stream;
+#define CPY(dst, src, cnt, T)                                                                  \
+    do {                                                                                       \
+        if ((cnt) > 0 && hipMemcpyAsync(dst, src, (size_t)(cnt) * sizeof(T),                  \
+                                        hipMemcpyHostToDevice, s) != hipSuccess)               \
+            return fail(NGP_ERR_STATE);                                                        \
+    } while (0)
+    CPY(j->progs, hp.data(), P, DevProgram);
+    CPY(j->t0, t, g.n0, double);
+    CPY(j->taux, h_taux.data(), g.da + m, double);
+    CPY(j->y0, h_y0.data(), ny * g.n0, double);
+    CPY(j->ya, h_ya.data(), (int64_t)ny * D * g.da, double);
+#undef CPY
+    if (hipStreamSynchronize(s) != hipSuccess) return fail(NGP_ERR_STATE);
+    *out = j;
+    return NGP_OK;
+}
+
+}  // namespace
+
+extern "C" ngp_status ngp_job_run(ngp_job *j) {
+    if (!j) return NGP_ERR_ARG;
+    ngp_ctx *c = j->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const JobGeom &g = j->g;
+    hipStream_t s = c->stream;
+    const DevSpec sp = dev_spec(c->spec);
+    EventTimer tm(c->profiling, s);
+    HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)g.B, s));
+    HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
+    void *Lbuf = nullptr, *dinv = nullptr;
+    if (g.n0 > 0) {
+        const size_t item_bytes = (size_t)g.item_stride * sizeof(double);
+        int Bc = (int)std::min<size_t>((size_t)g.B, std::max<size_t>(1, c->mem_cap / item_bytes));
+        ngp_status st = c->alloc(&Lbuf, item_bytes * (size_t)Bc);
+        while (st && Bc > 1) {  // back off if the device is fuller than expected
+            Bc = (Bc + 1) / 2;
+            st = c->alloc(&Lbuf, item_bytes * (size_t)Bc);
+        }
+        if (st) return st;
+        st = c->alloc(&dinv, sizeof(double) * (size_t)Bc * (NB / TB) * TB * TB);
+        if (st) { c->release(Lbuf); return st; }
+        const double nrows_aux = (double)g.naux;
+        for (int b0 = 0; b0 < g.B; b0 += Bc) {
+            const int bc = std::min(Bc, g.B - b0);
+            ChunkPtrs p{};
+            p.L = (double *)Lbuf;
+            p.dinv = (double *)dinv;
+            p.progs = j->progs + b0;
+            p.t0 = j->t0;
+            p.taux = j->taux;
+            p.y0 = j->y0 + (g.y_shared ? 0 : (int64_t)b0 * g.n0);
+            p.logdet = j->logdet + b0;
+            p.info = j->info + b0;
+            const double fill_elems =
+                (double)bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0);
+            tm.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, s); });
+            for (int jj = 0; jj < g.nb0; ++jj) {
+                const double k = (double)jj * NB;
+                tm.run(1, bc * ((double)NB * NB * k + (double)NB * NB * NB / 3.0),
+                       bc * 8.0 * (NB * k + 2.0 * NB * NB),
+                       [&] { launch_chol_diag(g, p, bc, jj, sp, s); });
+                const double rows = (double)(g.n0 - (jj + 1) * NB) + nrows_aux;
+                tm.run(0, bc * rows * (2.0 * NB * k + (double)NB * NB),
+                       bc * 8.0 * (rows * k + NB * k + 2.0 * rows * NB),
+                       [&] { launch_chol_col(g, p, bc, jj, sp, s); });
+            }
+            tm.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0, [&] {
+                launch_gram(g, (const double *)Lbuf, j->G + (int64_t)b0 * g.naux * g.naux, bc, s);
+            });
+        }
+    }
+    EpiPtrs e{};
+    e.progs = j->progs;
+    e.taux = j->taux;
+    e.G = j->G;
+    e.ya = j->ya;
+    e.logdet = j->logdet;
+    e.info = j->info;
+    e.work = j->work;
+    e.zbuf = j->zbuf;
+    e.logml_base = j->logml_base;
+    e.logml_full = j->logml_full;
+    e.mu = j->mu;
+    e.sigma = j->sigma;
+    e.work_stride = j->work_stride;
+    tm.run(3, 0.0, 0.0, [&] { launch_epilogue(g, e, sp, s); });
+    hipError_t err = hipStreamSynchronize(s);
+    if (err == hipSuccess) err = hipGetLastError();
+    tm.resolve(c->prof);
+    c->release(Lbuf);
+    c->release(dinv);
+    if (err != hipSuccess) return (ngp_status)err;
+    j->ran = true;
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_job_fetch(ngp_job *j, double *logml_base, double *logml_full, double *mu,
+                                    double *sigma, int32_t *info) {
+    if (!j) return NGP_ERR_ARG;
+    if (!j->ran) return NGP_ERR_STATE;
+    ngp_ctx *c = j->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const JobGeom &g = j->g;
+    hipStream_t s = c->stream;
+    if (logml_base)
+        HIPCHK(hipMemcpyAsync(logml_base, j->logml_base, sizeof(double) * (size_t)g.B,
+                              hipMemcpyDeviceToHost, s));
+    if (logml_full)
+        HIPCHK(hipMemcpyAsync(logml_full, j->logml_full, sizeof(double) * (size_t)g.B * g.D,
+                              hipMemcpyDeviceToHost, s));
+    if (mu && g.m > 0)
+        HIPCHK(hipMemcpyAsync(mu, j->mu, sizeof(double) * (size_t)g.B * g.D * g.m,
+                              hipMemcpyDeviceToHost, s));
+    if (sigma && g.m > 0)
+        HIPCHK(hipMemcpyAsync(sigma, j->sigma, sizeof(double) * (size_t)g.B * g.m * g.m,
+                              hipMemcpyDeviceToHost, s));
+    if (info)
+        HIPCHK(hipMemcpyAsync(info, j->info, sizeof(int32_t) * (size_t)g.B, hipMemcpyDeviceToHost,
+                              s));
+    HIPCHK(hipStreamSynchronize(s));
+    return NGP_OK;
+}
+
+extern "C" void ngp_job_destroy(ngp_job *j) {
+    if (!j) return;
+    {
+        std::lock_guard<std::mutex> lk(j->ctx->mu);
+        for (void *p : j->owned) j->ctx->release(p);
+    }
+    delete j;
+}
+
+// ---------------------------------------------------------------------------------------
+// staged + one-shot entry points
+// ---------------------------------------------------------------------------------------
+extern "C" ngp_status ngp_logml_stage(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
+                                      const double *t, const double *y, int64_t ldy,
+                                      ngp_job **job) {
+    if (n <= 0) return NGP_ERR_ARG;
+    static const double dummy = 0.0;
+    return stage_general(c, B, k, n, t, y, ldy, 0, &dummy, 1, &dummy, 0, 0, nullptr, 0, job);
+}
+
+extern "C" ngp_status ngp_predict_stage(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
+                                        const double *t, const double *y, int64_t ldy, int32_t m,
+                                        const double *t_new, int32_t noise_on_new, ngp_job **job) {
+    if (n <= 0 || m <= 0) return NGP_ERR_ARG;
+    static const double dummy = 0.0;
+    return stage_general(c, B, k, n, t, y, ldy, 0, &dummy, 1, &dummy, 0, m, t_new, noise_on_new,
+                         job);
+}
+
+extern "C" ngp_status ngp_nowcast_stage(ngp_ctx *c, int32_t P, const ngp_kernel *k, int32_t n,
+                                        const double *t, const double *y, int32_t d,
+                                        const double *t_add, int32_t D, const double *y_add,
+                                        int32_t m, const double *t_new, int32_t noise_on_new,
+                                        ngp_job **job) {
+    if (n <= 0 || d < 0 || D <= 0) return NGP_ERR_ARG;
+    static const double dummy = 0.0;
+    if (d == 0) { t_add = &dummy; y_add = &dummy; }
+    return stage_general(c, P, k, n, t, y, 0, d, t_add, D, y_add, 0, m, t_new, noise_on_new, job);
+}
+
+static ngp_status run_fetch_destroy(ngp_job *job, double *lb, double *lf, double *mu,
+                                    double *sigma, int32_t *info) {
+    ngp_status st = ngp_job_run(job);
+    if (!st) st = ngp_job_fetch(job, lb, lf, mu, sigma, info);
+    ngp_job_destroy(job);
+    return st;
+}
+
+extern "C" ngp_status ngp_logml_batch(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
+                                      const double *t, const double *y, int64_t ldy, double *logml,
+                                      int32_t *info) {
+    ngp_job *job = nullptr;
+    ngp_status st = ngp_logml_stage(c, B, k, n, t, y, ldy, &job);
+    if (st) return st;
+    return run_fetch_destroy(job, nullptr, logml, nullptr, nullptr, info);
+}
+
+extern "C" ngp_status ngp_predict_batch(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
+                                        const double *t, const double *y, int64_t ldy, int32_t m,
+                                        const double *t_new, int32_t noise_on_new, double *mu,
+                                        double *sigma, double *logml, int32_t *info) {
+    ngp_job *job = nullptr;
+    ngp_status st = ngp_predict_stage(c, B, k, n, t, y, ldy, m, t_new, noise_on_new, &job);
+    if (st) return st;
+    return run_fetch_destroy(job, nullptr, logml, mu, sigma, info);
+}
+
+extern "C" ngp_status ngp_nowcast_batch(ngp_ctx *c, int32_t P, const ngp_kernel *k, int32_t n,
+                                        const double *t, const double *y, int32_t d,
+                                        const double *t_add, int32_t D, const double *y_add,
+                                        int32_t m, const double *t_new, int32_t noise_on_new,
+                                        double *logml_base, double *logml_full, double *mu,
+                                        double *sigma, int32_t *info) {
+    ngp_job *job = nullptr;
+    ngp_status st = ngp_nowcast_stage(c, P, k, n, t, y, d, t_add, D, y_add, m, t_new, noise_on_new,
+                                      &job);
+    if (st) return st;
+    return run_fetch_destroy(job, logml_base, logml_full, mu, sigma, info);
+}
+
+extern "C" ngp_status ngp_cov_batch(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n1,
+                                    const double *t1, int32_t n2, const double *t2,
+                                    int32_t add_diag, double *out) {
+    if (!c || !kernels || !t1 || !t2 || !out || B <= 0 || n1 <= 0 || n2 <= 0) return NGP_ERR_ARG;
+    std::vector<DevProgram> hp((size_t)B);
+    for (int i = 0; i < B; ++i) {
+        ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], nullptr);
+        if (st) return st;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    void *dp = nullptr, *d1 = nullptr, *d2 = nullptr, *dout = nullptr;
+    const size_t nout = (size_t)B * n1 * n2;
+    ngp_status st;
+    if ((st = c->alloc(&dp, sizeof(DevProgram) * (size_t)B)) ||
+        (st = c->alloc(&d1, sizeof(double) * (size_t)n1)) ||
+        (st = c->alloc(&d2, sizeof(double) * (size_t)n2)) ||
+        (st = c->alloc(&dout, sizeof(double) * nout))) {
+        c->release(dp); c->release(d1); c->release(d2); c->release(dout);
+        return st;
+    }
+    hipStream_t s = c->stream;
+    hipError_t e = hipMemcpyAsync(dp, hp.data(), sizeof(DevProgram) * (size_t)B,
+                                  hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d1, t1, sizeof(double) * (size_t)n1, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d2, t2, sizeof(double) * (size_t)n2, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        EventTimer tm(c->profiling, s);
+        tm.run(4, 0.0, 8.0 * (double)nout, [&] {
+            launch_cov((const DevProgram *)dp, B, (const double *)d1, n1, (const double *)d2, n2,
+                       add_diag, (double *)dout, dev_spec(c->spec), s);
+        });
+        e = hipMemcpyAsync(out, dout, sizeof(double) * nout, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        tm.resolve(c->prof);
+    }
+    c->release(dp); c->release(d1); c->release(d2); c->release(dout);
+    return e == hipSuccess ? NGP_OK : (ngp_status)e;
+}
+
+extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *, int32_t, const ngp_kernel *, int32_t,
+                                           const double *, const double *, int64_t, double *,
+                                           double *, int32_t *) {
+    return NGP_ERR_STATE;  // gradient path: see ngp_grad.hip once built
+}
+
+extern "C" ngp_status ngp_weights_normalize(int32_t P, const double *logw, double *w_norm,
+                                            double *ess, double *log_norm) {
+    if (P <= 0 || !logw) return NGP_ERR_ARG;
+    double mx = -INFINITY;
+    for (int i = 0; i < P; ++i)
+        if (logw[i] > mx) mx = logw[i];
+    if (!(mx > -INFINITY)) {
+        if (ess) *ess = NAN;
+        if (log_norm) *log_norm = -INFINITY;
+        if (w_norm) for (int i = 0; i < P; ++i) w_norm[i] = NAN;
+        return NGP_OK;
+    }
+    double sum = 0.0;
+    for (int i = 0; i < P; ++i) sum += std::exp(logw[i] - mx);
+    double sq = 0.0;
+    for (int i = 0; i < P; ++i) {
+        const double w = std::exp(logw[i] - mx) / sum;
+        if (w_norm) w_norm[i] = w;
+        sq += w * w;
+    }
+    if (ess) *ess = 1.0 / sq;
+    if (log_norm) *log_norm = mx + std::log(sum);
+    return NGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// microbenchmarks / self tests
+// ---------------------------------------------------------------------------------------
+extern "C" ngp_status ngp_microbench_mfma_f64(ngp_ctx *c, int32_t iters, double *tflops) {
+    if (!c || !tflops || iters <= 0) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    iters = (iters + 3) / 4 * 4;
+    const int blocks = 256 * 4;  // 4 workgroups of 4 waves per CU
+    void *out = nullptr;
+    ngp_status st = c->alloc(&out, sizeof(double) * (size_t)blocks * 256);
+    if (st) return st;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    launch_mfma_bench((double *)out, iters, blocks, c->stream);  // warm-up
+    HIPCHK(hipEventRecord(a, c->stream));
+    launch_mfma_bench((double *)out, iters, blocks, c->stream);
+    HIPCHK(hipEventRecord(b, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    c->release(out);
+    *tflops = (double)blocks * 4.0 * (double)iters * 2048.0 / ((double)ms * 1e-3) * 1e-12;
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_microbench_hbm(ngp_ctx *c, int64_t bytes, double *write_gbs,
+                                         double *copy_gbs) {
+    if (!c || bytes < 4096) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t n = bytes / 16 * 2;
+    void *a = nullptr, *b = nullptr;
+    ngp_status st = c->alloc(&a, (size_t)n * 8);
+    if (st) return st;
+    st = c->alloc(&b, (size_t)n * 8);
+    if (st) { c->release(a); return st; }
+    hipEvent_t e0, e1, e2;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventCreate(&e2));
+    launch_stream_write((double *)a, n, c->stream);
+    launch_stream_copy((double *)b, (const double *)a, n, c->stream);
+    HIPCHK(hipEventRecord(e0, c->stream));
+    launch_stream_write((double *)a, n, c->stream);
+    HIPCHK(hipEventRecord(e1, c->stream));
+    launch_stream_copy((double *)b, (const double *)a, n, c->stream);
+    HIPCHK(hipEventRecord(e2, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float w = 0.f, cp = 0.f;
+    HIPCHK(hipEventElapsedTime(&w, e0, e1));
+    HIPCHK(hipEventElapsedTime(&cp, e1, e2));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    c->release(a); c->release(b);
+    if (write_gbs) *write_gbs = (double)n * 8.0 / ((double)w * 1e-3) * 1e-9;
+    if (copy_gbs) *copy_gbs = 2.0 * (double)n * 8.0 / ((double)cp * 1e-3) * 1e-9;
+    return NGP_OK;
+}
+
+// D = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 using the operand maps the kernels
+// assume; the caller compares with A @ B (asymmetric data) — tests/test_gpu_parity.py.
+extern "C" ngp_status ngp_selftest_mfma_layout(ngp_ctx *c, const double *A, const double *Bm,
+                                               double *D) {
+    if (!c || !A || !Bm || !D) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    void *da = nullptr, *db = nullptr, *dd = nullptr;
+    ngp_status st;
+    if ((st = c->alloc(&da, 64 * 8)) || (st = c->alloc(&db, 64 * 8)) ||
+        (st = c->alloc(&dd, 256 * 8))) {
+        c->release(da); c->release(db); c->release(dd);
+        return st;
+    }
+    hipError_t e = hipMemcpyAsync(da, A, 64 * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db, Bm, 64 * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_mfma_layout_probe((const double *)da, (const double *)db, (double *)dd, c->stream);
+        e = hipMemcpyAsync(D, dd, 256 * 8, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    c->release(da); c->release(db); c->release(dd);
+    return e == hipSuccess ? NGP_OK : (ngp_status)e;
+}

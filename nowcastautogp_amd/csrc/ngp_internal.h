@@ -1,0 +1,95 @@
+// ngp_internal.h — shared between the kernel TU (ngp_kernels.hip) and the host/C-ABI TU
+// (ngp_api.hip).  gfx950 only; no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ngp.h"
+
+namespace ngp {
+
+constexpr int NB = 64;        // block-column width of the left-looking factorisation
+constexpr int TB = 16;        // MFMA tile edge (v_mfma_f64_16x16x4_f64)
+constexpr int DEV_STACK = 8;  // register-resident evaluation stack depth on the device
+
+// device opcode = host opcode, plus CP with its two operands in swapped stack order
+// (the host reorders children so the evaluation stack never exceeds DEV_STACK)
+constexpr int OP_CP_SWAPPED = 9;
+
+// One particle's kernel, flattened for the device.  Copied into LDS by every workgroup that
+// needs it; ops are uniform across the workgroup so the interpreter never diverges.
+struct DevProgram {
+    int32_t n_ops;
+    int32_t n_params;
+    double  noise;               // observation-noise variance (jitter is in the spec)
+    uint8_t ops[NGP_MAX_OPS];
+    double  params[NGP_MAX_PARAMS];
+};
+static_assert(sizeof(DevProgram) % 8 == 0, "DevProgram is copied as 8-byte words");
+
+struct DevSpec {
+    int32_t se_form, periodic_form, cp_form, pad;
+    double  jitter;
+};
+
+// Geometry of one staged job on the device (all items share times; see ngp_api.hip).
+struct JobGeom {
+    int32_t B;         // items (kernels)
+    int32_t n0;        // main block: multiple of NB training points
+    int32_t nb0;       // n0 / NB
+    int32_t da;        // appended rows: tail (n - n0) + d nowcast points
+    int32_t tail;      // n - n0: appended rows that belong to the base data
+    int32_t m;         // forecast points
+    int32_t naux;      // da + m + 1 (last aux row carries y)
+    int32_t naux_pad;  // naux rounded up to a multiple of NB
+    int32_t D;         // scenarios
+    int32_t d;         // nowcast points per scenario
+    int32_t noise_on_new;
+    int32_t y_shared;  // 1: one base y / ya for all items
+    int64_t ld;        // row stride of the factor storage (= n0)
+    int64_t item_stride;  // elements per item in the factor storage
+};
+
+struct ChunkPtrs {
+    double       *L;      // [Bc][(n0 + naux_pad) x n0] factor + aux rows, row-major
+    double       *dinv;   // [Bc][NB/TB][TB x TB] diagonal-block inverses of the current step
+    const DevProgram *progs;  // [Bc] (already offset to the chunk)
+    const double *t0;     // [n0]
+    const double *taux;   // [da + m] times of the aux rows (appended then forecast)
+    const double *y0;     // [Bc or 1][n0] (already offset to the chunk when per item)
+    double       *logdet; // [Bc]
+    int32_t      *info;   // [Bc]
+};
+
+struct EpiPtrs {
+    const DevProgram *progs;  // [B]
+    const double *taux;       // [da + m]
+    const double *G;          // [B][naux x naux]
+    const double *ya;         // [B or 1][D][da]
+    const double *logdet;     // [B]
+    int32_t      *info;       // [B]
+    double       *work;       // [B][work_stride]
+    double       *zbuf;       // [B][D][da]
+    double       *logml_base; // [B]
+    double       *logml_full; // [B][D]
+    double       *mu;         // [B][D][m]
+    double       *sigma;      // [B][m][m]
+    int64_t       work_stride;
+};
+
+// ---- launchers implemented in ngp_kernels.hip ------------------------------------------
+void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s);
+void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, const DevSpec &sp,
+                      hipStream_t s);
+void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, const DevSpec &sp,
+                     hipStream_t s);
+void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s);
+void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipStream_t s);
+void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2,
+                int n2, int add_diag, double *out, const DevSpec &sp, hipStream_t s);
+void launch_mfma_bench(double *out, int iters, int blocks, hipStream_t s);
+void launch_mfma_layout_probe(const double *A, const double *Bm, double *Dout, hipStream_t s);
+void launch_stream_write(double *dst, int64_t n, hipStream_t s);
+void launch_stream_copy(double *dst, const double *src, int64_t n, hipStream_t s);
+
+}  // namespace ngp
