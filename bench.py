@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path on BASELINE.json's headline configuration.
+
+Workload (config C3): n = 2048 weekly points, P = 64 SMC particles x D = 200 nowcast scenarios
+(d = 1 appended point, m = 9 forecast points), fp64, synthetic (SURVEY.md section 8d recipe).
+
+A *step* is one pass of the hot path over the whole batch: for every (particle, scenario) item
+the covariance matrix at n+d points is assembled from the item's kernel tree, factorised, and
+its log marginal likelihood + predictive mean/covariance are produced — i.e. exactly the work
+the reference's forecast_with_nowcasts does per scenario task (reference
+src/forecasting.jl:246-268: add_data! then predict_mvn on a deep-copied model).  In the headline
+("distinct") mode every one of the 12,800 items carries its own kernel parameters (the
+per-draw HMC-refined parameters of forecast_n_hmc, src/forecasting.jl:176-181), so nothing is
+deduplicated: 12,800 factorisations per step.  ``value`` = items / second, whole job.
+
+Also reported (extra keys, never mixed into ``value``/``roofline``): the shared-K mode the
+default n_mcmc = n_hmc = 0 path allows (one factorisation per particle, scenarios as extra
+right-hand sides), as wall-clock per forecast and reference-equivalent evaluations per second.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched by torchrun, one
+rank per GPU; weak scaling (every rank owns its own 64 particles x 200 scenarios); the only
+collective is the all-gather of particle log-weights for the resampling normalisation.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet, dense fp64 matrix (not in the local guide)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md chip table (spec)
+
+
+def F_logml(n):
+    """Algorithmic flops of one logml evaluation: potrf + solve + quad."""
+    return n ** 3 / 3.0 + 2.0 * n ** 2
+
+
+def cpu_baseline(w, progs, Y, sample_items, threads):
+    """The numpy/LAPACK oracle ("port"), run as the reference runs: BLAS threads = 1
+    (src/forecasting.jl:114-123), one worker thread per host core over items."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from threadpoolctl import threadpool_limits
+
+    from oracle import oracle_np
+    tt = np.concatenate([w.t, w.t_add])
+    idx = list(range(0, len(progs), max(1, len(progs) // sample_items)))[:sample_items]
+
+    def one(i):
+        mu, sg, lm, info = oracle_np.predict(progs[i], tt, Y[i], w.t_new)
+        return lm
+
+    with threadpool_limits(limits=1):
+        one(idx[0])  # warm
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            res = list(ex.map(one, idx))
+        dt = time.perf_counter() - t0
+    return len(idx) / dt, len(idx), dt, res, idx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--particles", type=int, default=None)
+    ap.add_argument("--scenarios", type=int, default=None)
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="items in the CPU sample (0: auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the GP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from nowcastautogp_amd import _lib
+    from nowcastautogp_amd.distributed import normalize_log_weights
+    from nowcastautogp_amd.synthetic import jitter_programs, make_workload
+
+    w = make_workload(args.config, n=args.n, P=args.particles, D=args.scenarios, seed_offset=rank)
+    P, D, n, d, m = len(w.programs), w.y_add.shape[0], w.n, w.t_add.size, w.t_new.size
+    rng = np.random.Generator(np.random.PCG64(99 + rank))
+    progs = jitter_programs(w.programs, D, rng)           # item = p * D + s, all kernels distinct
+    Y = np.empty((P * D, n + d))
+    Y[:, :n] = w.y
+    Y[:, n:] = np.tile(w.y_add, (P, 1))
+    tt = np.concatenate([w.t, w.t_add])
+    B = P * D
+
+    ctx = _lib.Context(local_rank)
+    job = ctx.stage_predict(progs, tt, Y, w.t_new)        # inputs now resident in HBM
+    logw_prev = np.zeros((P, D))
+
+    def step():
+        job.run()
+        out = job.fetch()
+        # add_data! weight update + maybe_resample! normalisation: per scenario over ALL particles
+        logw = logw_prev + out["logml_full"].reshape(P, D)
+        return out, normalize_log_weights(logw, device=torch.device("cuda", local_rank))
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, (wn, ess) = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile_get()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    bad = int((out["info"] != 0).sum())
+
+    # shared-K mode of the same workload (default n_mcmc = n_hmc = 0 path), rank-local, untimed
+    # against `value`: reported separately
+    job2 = ctx.stage_nowcast(w.programs, w.t, w.y, w.t_add, w.y_add, w.t_new)
+    job2.run()
+    ts = time.perf_counter()
+    for _ in range(3):
+        job2.run()
+        job2.fetch()
+    shared_ms = (time.perf_counter() - ts) / 3 * 1e3
+    job2.close()
+
+    if rank == 0:
+        col = prof.get("chol_col", dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
+        total_ms = sum(v["ms"] for v in prof.values())
+        ach = col["flops"] / (col["ms"] * 1e-3) * 1e-12 if col["ms"] else 0.0
+        res = {
+            "metric": "particle-logml/s (fit+forecast hot path: covariance assembly + Cholesky + "
+                      "logml + predictive per (particle, scenario) item), n=2048 64-particle SMC",
+            "value": B * world * args.steps / elapsed,
+            "unit": "particle-logml/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: n={n}+{d} points, {P} particles x {D} nowcast "
+                                   f"scenarios per GPU, m={m} forecast points, every item its own "
+                                   "kernel parameters (no dedupe)",
+                       "items_per_gpu": B, "parallelism": f"particles sharded x{world}"},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "chol_col_kernel (v_mfma_f64_16x16x4_f64 trailing update + in-register "
+                          "triangular solve)",
+                "achieved": ach,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "launches": col["launches"],
+                "avg_launch_ms": col["ms"] / max(col["launches"], 1),
+                "algorithmic_flops_per_item": F_logml(n + d),
+                "whole_path_tflops": B * args.steps * F_logml(n + d) / (total_ms * 1e-3) * 1e-12
+                if total_ms else 0.0,
+            },
+            "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+            "failed_items": bad,
+            "shared_k_mode": {
+                "what": "one factorisation per particle, scenarios as extra right-hand sides "
+                        "(legal when n_mcmc = n_hmc = 0: src/create_nowcast_data.jl:36-37)",
+                "ms_per_forecast": shared_ms,
+                "reference_equivalent_evals_per_s": 2 * B / (shared_ms * 1e-3),
+            },
+        }
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            sample = args.cpu_sample or max(2 * cores, 8)
+            rate, ns, dt, ref_lm, idx = cpu_baseline(w, progs, Y, sample, cores)
+            err = float(np.max(np.abs(out["logml_full"].reshape(-1)[idx] - np.array(ref_lm))
+                               / np.abs(np.array(ref_lm))))
+            res["cpu_baseline"] = {
+                "value": rate, "unit": "particle-logml/s", "cores": cores, "kind": "port",
+                "sample": f"{ns} of the {B} items (numpy/scipy OpenBLAS oracle, BLAS threads=1, "
+                          f"{cores} worker threads), {dt:.1f} s",
+                "max_rel_logml_diff_vs_gpu_on_sample": err,
+            }
+            res["speedup_vs_cpu_port"] = res["value"] / rate
+        print(json.dumps(res))
+    job.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -217,6 +217,10 @@ ngp_status ngp_profile_get(ngp_ctx *ctx, ngp_profile *out);
 /* fp64 MFMA issue-rate microbenchmark (v_mfma_f64_16x16x4_f64); returns the
  * measured dense TFLOP/s over `iters` back-to-back MFMAs per wave.            */
 ngp_status ngp_microbench_mfma_f64(ngp_ctx *ctx, int32_t iters, double *tflops);
+/* Same loop with in-kernel stamps: out[0] TFLOP/s (wall), out[1] median shader cycles per MFMA
+ * per wave, out[2] median shader clock held under load in GHz, out[3] waves per SIMD.      */
+ngp_status ngp_microbench_mfma_f64_detail(ngp_ctx *ctx, int32_t iters, int32_t blocks_per_cu,
+                                          double *out);
 /* One v_mfma_f64_16x16x4_f64 through the operand maps the kernels assume:
  * D[16x16] = A[16x4] B[4x16], all row-major; the caller compares with A @ B.   */
 ngp_status ngp_selftest_mfma_layout(ngp_ctx *ctx, const double *A, const double *B, double *D);

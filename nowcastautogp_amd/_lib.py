@@ -27,7 +27,7 @@ SYMBOLS = (
     "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
     "ngp_job_destroy", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
-    "ngp_microbench_mfma_f64", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
+    "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
 )
 
 
@@ -90,6 +90,7 @@ def load():
         "ngp_profile_reset": (i32, [vp]),
         "ngp_profile_get": (i32, [vp, C.POINTER(NgpProfile)]),
         "ngp_microbench_mfma_f64": (i32, [vp, i32, f64p]),
+        "ngp_microbench_mfma_f64_detail": (i32, [vp, i32, i32, f64p]),
         "ngp_microbench_hbm": (i32, [vp, i64, f64p, f64p]),
         "ngp_selftest_mfma_layout": (i32, [vp, f64p, f64p, f64p]),
     }
@@ -321,6 +322,13 @@ class Context:
         v = C.c_double()
         _chk(load().ngp_microbench_mfma_f64(self._h, iters, C.byref(v)), "ngp_microbench_mfma_f64")
         return float(v.value)
+
+    def microbench_mfma_f64_detail(self, iters=20000, blocks_per_cu=1) -> dict:
+        out = np.empty(4)
+        _chk(load().ngp_microbench_mfma_f64_detail(self._h, iters, blocks_per_cu, dptr(out)),
+             "ngp_microbench_mfma_f64_detail")
+        return dict(tflops=out[0], cycles_per_mfma=out[1], clock_ghz=out[2],
+                    waves_per_simd=int(out[3]))
 
     def microbench_hbm(self, nbytes=1 << 30):
         w, c = C.c_double(), C.c_double()

@@ -704,6 +704,49 @@ extern "C" ngp_status ngp_microbench_mfma_f64(ngp_ctx *c, int32_t iters, double 
     return NGP_OK;
 }
 
+// out[0] TFLOP/s (wall), out[1] median shader cycles per MFMA per wave, out[2] median effective
+// shader clock in GHz (s_memtime / s_memrealtime), out[3] waves per SIMD used
+extern "C" ngp_status ngp_microbench_mfma_f64_detail(ngp_ctx *c, int32_t iters,
+                                                     int32_t blocks_per_cu, double *out) {
+    if (!c || !out || iters <= 0 || blocks_per_cu <= 0 || blocks_per_cu > 8) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    iters = (iters + 3) / 4 * 4;
+    const int blocks = 256 * blocks_per_cu;
+    const int waves = blocks * 4;
+    void *st = nullptr;
+    ngp_status s0 = c->alloc(&st, sizeof(unsigned long long) * 2 * (size_t)waves);
+    if (s0) return s0;
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    launch_mfma_bench_detail((unsigned long long *)st, iters, blocks, c->stream);
+    HIPCHK(hipEventRecord(a, c->stream));
+    launch_mfma_bench_detail((unsigned long long *)st, iters, blocks, c->stream);
+    HIPCHK(hipEventRecord(b, c->stream));
+    std::vector<unsigned long long> h(2 * (size_t)waves);
+    HIPCHK(hipMemcpyAsync(h.data(), st, sizeof(unsigned long long) * h.size(),
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    c->release(st);
+    std::vector<double> cyc((size_t)waves), ghz((size_t)waves);
+    for (int w = 0; w < waves; ++w) {
+        cyc[(size_t)w] = (double)h[2 * (size_t)w] / (double)iters;
+        ghz[(size_t)w] = (double)h[2 * (size_t)w] / ((double)h[2 * (size_t)w + 1] * 10.0);
+    }
+    std::nth_element(cyc.begin(), cyc.begin() + waves / 2, cyc.end());
+    std::nth_element(ghz.begin(), ghz.begin() + waves / 2, ghz.end());
+    out[0] = (double)waves * (double)iters * 2048.0 / ((double)ms * 1e-3) * 1e-12;
+    out[1] = cyc[(size_t)waves / 2];
+    out[2] = ghz[(size_t)waves / 2];
+    out[3] = (double)blocks_per_cu;
+    return NGP_OK;
+}
+
 extern "C" ngp_status ngp_microbench_hbm(ngp_ctx *c, int64_t bytes, double *write_gbs,
                                          double *copy_gbs) {
     if (!c || bytes < 4096) return NGP_ERR_ARG;

@@ -88,6 +88,7 @@ void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipS
 void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2,
                 int n2, int add_diag, double *out, const DevSpec &sp, hipStream_t s);
 void launch_mfma_bench(double *out, int iters, int blocks, hipStream_t s);
+void launch_mfma_bench_detail(unsigned long long *stamps, int iters, int blocks, hipStream_t s);
 void launch_mfma_layout_probe(const double *A, const double *Bm, double *Dout, hipStream_t s);
 void launch_stream_write(double *dst, int64_t n, hipStream_t s);
 void launch_stream_copy(double *dst, const double *src, int64_t n, hipStream_t s);

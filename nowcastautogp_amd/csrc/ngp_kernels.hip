@@ -536,6 +536,30 @@ __global__ __launch_bounds__(256) void mfma_bench_kernel(double *out, int iters)
     if (r[0] + r[1] + r[2] + r[3] == -1.0) out[blockIdx.x * 256 + threadIdx.x] = r[0];
 }
 
+// per-wave shader-clock cycles (s_memtime) and 100 MHz wall ticks (s_memrealtime) around the loop
+__global__ __launch_bounds__(256) void mfma_bench_detail_kernel(unsigned long long *stamps,
+                                                                int iters) {
+    f64x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i += 4) {
+        c0 = mfma64(a, b, c0);
+        c1 = mfma64(a, b, c1);
+        c2 = mfma64(a, b, c2);
+        c3 = mfma64(a, b, c3);
+    }
+    const f64x4 r = c0 + c1 + c2 + c3;
+    asm volatile("" ::"v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+        stamps[2 * w] = t1 - t0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+}
+
 __global__ void mfma_layout_probe_kernel(const double *A, const double *Bm, double *Dout) {
     const int l = threadIdx.x;
     const double a = A[(l & 15) * 4 + (l >> 4)];    // A[m][k], 16x4 row-major
@@ -602,6 +626,9 @@ void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const 
 
 void launch_mfma_bench(double *out, int iters, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(mfma_bench_kernel, dim3(blocks), dim3(256), 0, s, out, iters);
+}
+void launch_mfma_bench_detail(unsigned long long *stamps, int iters, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(mfma_bench_detail_kernel, dim3(blocks), dim3(256), 0, s, stamps, iters);
 }
 void launch_mfma_layout_probe(const double *A, const double *Bm, double *Dout, hipStream_t s) {
     hipLaunchKernelGGL(mfma_layout_probe_kernel, dim3(1), dim3(64), 0, s, A, Bm, Dout);
