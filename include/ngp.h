@@ -221,8 +221,10 @@ ngp_status ngp_microbench_mfma_f64(ngp_ctx *ctx, int32_t iters, double *tflops);
  * per wave, out[2] median shader clock held under load in GHz, out[3] waves per SIMD.      */
 ngp_status ngp_microbench_mfma_f64_detail(ngp_ctx *ctx, int32_t iters, int32_t blocks_per_cu,
                                           double *out);
-/* One v_mfma_f64_16x16x4_f64 through the operand maps the kernels assume:
- * D[16x16] = A[16x4] B[4x16], all row-major; the caller compares with A @ B.   */
+/* MFMA operand-map self test, all row-major: D[0:256] = A[16x4] B[4x16] through one
+ * v_mfma_f64_16x16x4_f64; D[256:512] = the same product through four DPP-rotated
+ * v_mfma_f64_4x4x4_4b_f64 gathered back to the 16x16x4 C/D layout (the k-loop fast path).
+ * The caller compares both halves with A @ B.  D must hold 512 doubles.                 */
 ngp_status ngp_selftest_mfma_layout(ngp_ctx *ctx, const double *A, const double *B, double *D);
 /* HBM streaming-write microbenchmark (GB/s) used to anchor the fill roofline. */
 ngp_status ngp_microbench_hbm(ngp_ctx *ctx, int64_t bytes, double *write_gbs, double *copy_gbs);

@@ -337,11 +337,12 @@ class Context:
         return float(w.value), float(c.value)
 
     def selftest_mfma_layout(self, A, B):
+        """returns (D via v_mfma_f64_16x16x4, D via 4 rotated v_mfma_f64_4x4x4 + gather)"""
         A, B = as_f64(A).reshape(16, 4), as_f64(B).reshape(4, 16)
-        D = np.empty((16, 16))
+        D = np.empty((2, 16, 16))
         _chk(load().ngp_selftest_mfma_layout(self._h, dptr(A), dptr(B), dptr(D)),
              "ngp_selftest_mfma_layout")
-        return D
+        return D[0], D[1]
 
 
 def raise_if_not_posdef(info: np.ndarray):

@@ -56,7 +56,8 @@ struct TNode {
 // (Sethi-Ullman): the device keeps its evaluation stack in DEV_STACK registers.  Plus/Times
 // commute bit-exactly in IEEE arithmetic; ChangePoint gets a swapped-operand opcode.
 // perm[device param index] = caller's param index.
-ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int> *perm) {
+ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int> *perm,
+                           int *n_stat = nullptr, int *n_cp = nullptr) {
     ngp_status st = check_program(k);
     if (st) return st;
     std::vector<TNode> nodes;
@@ -80,7 +81,7 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
     out->n_ops = k->n_ops;
     out->n_params = k->n_params;
     out->noise = k->noise;
-    int no = 0, np = 0;
+    int no = 0, np = 0, nstat = 0, ncp = 0;
     if (perm) perm->clear();
     // iterative post-order with child reordering
     struct Frame { int node, stage; };
@@ -92,6 +93,8 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
         if (nd.op < NGP_OP_PLUS || f.stage == 2) {
             int op = nd.op;
             if (op == NGP_OP_CHANGEPOINT && swap) op = OP_CP_SWAPPED;
+            if (nd.op >= NGP_OP_SQEXP && nd.op <= NGP_OP_PERIODIC) out->slot[no] = (uint8_t)nstat++;
+            if (nd.op == NGP_OP_CHANGEPOINT) out->slot[no] = (uint8_t)ncp++;
             out->ops[no++] = (uint8_t)op;
             for (int q = 0; q < k_nparams[nd.op]; ++q) {
                 out->params[np++] = k->params[nd.pfirst + q];
@@ -106,7 +109,52 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
             fs.push_back({swap ? nd.left : nd.right, 0});
         }
     }
+    if (n_stat) *n_stat = nstat;
+    if (n_cp) *n_cp = ncp;
     return NGP_OK;
+}
+
+// Do all times sit on a lattice t = tmin + q h (true for integer-day dates after the [0,1]
+// rescale)?  Floating-point Euclid over the gaps; accepted only if every point is reproduced to a
+// few ulp, so a table value at distance k h equals the direct evaluation to rounding.
+bool detect_lattice(const std::vector<double> &t, double *h_out, std::vector<int32_t> *q,
+                    int *R_out) {
+    const size_t n = t.size();
+    if (n < 2) return false;
+    double tmin = t[0], tmax = t[0];
+    for (double v : t) { tmin = std::min(tmin, v); tmax = std::max(tmax, v); }
+    if (!(tmax > tmin) || !std::isfinite(tmax) || !std::isfinite(tmin)) return false;
+    const double span = tmax - tmin;
+    const double tol = 1e-9 * span;
+    double g = 0.0;
+    for (double v : t) {
+        double a = v - tmin;
+        if (a <= tol) continue;
+        if (g == 0.0) { g = a; continue; }
+        double x = g, y = a;          // Euclid with snapping
+        for (int it = 0; it < 64 && y > tol; ++it) {
+            double r = std::fmod(x, y);
+            if (y - r <= tol) r = 0.0;
+            x = y;
+            y = r;
+        }
+        g = x;
+        if (g < span / (double)(1 << 20)) return false;
+    }
+    if (g <= 0.0) return false;
+    const double qmaxd = std::round(span / g);
+    if (qmaxd < 1.0 || qmaxd > (double)(1 << 20)) return false;
+    const double h = span / qmaxd;
+    const double scale = std::max(std::max(std::fabs(tmin), std::fabs(tmax)), 1.0);
+    q->resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const double qi = std::round((t[i] - tmin) / h);
+        if (std::fabs((t[i] - tmin) - qi * h) > 16.0 * 2.220446049250313e-16 * scale) return false;
+        (*q)[i] = (int32_t)qi;
+    }
+    *h_out = h;
+    *R_out = (int)qmaxd + 1;
+    return true;
 }
 
 }  // namespace
@@ -117,6 +165,8 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
 struct ngp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;          // diag-ahead tiles run beside the main schedule
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ngp_spec spec{};
     std::mutex mu;
     bool profiling = false;
@@ -205,6 +255,12 @@ extern "C" ngp_status ngp_ctx_create(int32_t device, ngp_ctx **out) {
         delete c;
         return (ngp_status)e;
     }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return NGP_ERR_NO_DEVICE;
+    }
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->mem_cap = (size_t)(0.6 * (double)fr);
     else c->mem_cap = (size_t)8 << 30;
@@ -219,6 +275,9 @@ extern "C" void ngp_ctx_destroy(ngp_ctx *c) {
     for (auto &kv : c->free_blocks) (void)hipFree(kv.second);
     for (auto &kv : c->live) (void)hipFree(kv.first);
     (void)hipStreamDestroy(c->stream);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -268,7 +327,7 @@ struct ngp_job {
     DevProgram *progs = nullptr;
     double *t0 = nullptr, *taux = nullptr, *y0 = nullptr, *ya = nullptr;
     double *logdet = nullptr, *G = nullptr, *work = nullptr, *zbuf = nullptr;
-    int32_t *info = nullptr;
+    int32_t *info = nullptr, *qpts = nullptr;
     double *logml_base = nullptr, *logml_full = nullptr, *mu = nullptr, *sigma = nullptr;
     int64_t work_stride = 0;
     std::vector<void *> owned;
@@ -329,9 +388,13 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
         return NGP_ERR_ARG;
     *out = nullptr;
     std::vector<DevProgram> hp((size_t)P);
+    int maxstat = 0, maxcp = 0;
     for (int i = 0; i < P; ++i) {
-        ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], nullptr);
+        int ns = 0, nc = 0;
+        ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], nullptr, &ns, &nc);
         if (st) return st;
+        maxstat = std::max(maxstat, ns);
+        maxcp = std::max(maxcp, nc);
     }
     JobGeom g{};
     g.B = P;
@@ -349,6 +412,23 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     g.y_shared = (ldy == 0) ? 1 : 0;
     g.ld = g.n0;
     g.item_stride = (int64_t)(g.n0 + g.naux_pad) * g.n0;
+    g.npts = g.n0 + g.da + m;
+    g.maxstat = std::max(maxstat, 1);
+    g.maxcp = std::max(maxcp, 1);
+    std::vector<int32_t> h_q;
+    if (g.n0 > 0) {
+        std::vector<double> allt((size_t)g.npts);
+        for (int i = 0; i < n; ++i) allt[(size_t)i] = t[i];
+        for (int a = 0; a < d; ++a) allt[(size_t)(n + a)] = t_add[a];
+        for (int i = 0; i < m; ++i) allt[(size_t)(n + d + i)] = t_new[i];
+        double hh = 0.0;
+        int R = 0;
+        if (detect_lattice(allt, &hh, &h_q, &R)) {
+            g.lattice = 1;
+            g.h = hh;
+            g.R = R;
+        }
+    }
 
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
@@ -385,6 +465,7 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     if ((st = job_alloc(j, &j->taux, h_taux.size()))) return fail(st);
     if ((st = job_alloc(j, &j->y0, h_y0.size()))) return fail(st);
     if ((st = job_alloc(j, &j->ya, h_ya.size()))) return fail(st);
+    if (g.lattice && (st = job_alloc(j, &j->qpts, (size_t)g.npts))) return fail(st);
     if ((st = job_alloc(j, &j->logdet, (size_t)P))) return fail(st);
     if ((st = job_alloc(j, &j->info, (size_t)P))) return fail(st);
     if ((st = job_alloc(j, &j->G, (size_t)P * g.naux * g.naux))) return fail(st);
@@ -410,6 +491,7 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     CPY(j->taux, h_taux.data(), g.da + m, double);
     CPY(j->y0, h_y0.data(), ny * g.n0, double);
     CPY(j->ya, h_ya.data(), (int64_t)ny * D * g.da, double);
+    if (g.lattice) CPY(j->qpts, h_q.data(), g.npts, int32_t);
 #undef CPY
     if (hipStreamSynchronize(s) != hipSuccess) return fail(NGP_ERR_STATE);
     *out = j;
@@ -429,18 +511,23 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     EventTimer tm(c->profiling, s);
     HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)g.B, s));
     HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
-    void *Lbuf = nullptr, *dinv = nullptr;
+    void *Lbuf = nullptr, *dinv = nullptr, *tab = nullptr, *sig = nullptr;
     if (g.n0 > 0) {
-        const size_t item_bytes = (size_t)g.item_stride * sizeof(double);
+        const size_t tab_bytes = g.lattice ? sizeof(double) * (size_t)g.maxstat * g.R : 0;
+        const size_t sig_bytes = g.lattice ? sizeof(double) * (size_t)g.maxcp * g.npts : 0;
+        const size_t item_bytes = (size_t)g.item_stride * sizeof(double) + tab_bytes + sig_bytes;
         int Bc = (int)std::min<size_t>((size_t)g.B, std::max<size_t>(1, c->mem_cap / item_bytes));
-        ngp_status st = c->alloc(&Lbuf, item_bytes * (size_t)Bc);
+        const size_t l_bytes = (size_t)g.item_stride * sizeof(double);
+        ngp_status st = c->alloc(&Lbuf, l_bytes * (size_t)Bc);
         while (st && Bc > 1) {  // back off if the device is fuller than expected
             Bc = (Bc + 1) / 2;
-            st = c->alloc(&Lbuf, item_bytes * (size_t)Bc);
+            st = c->alloc(&Lbuf, l_bytes * (size_t)Bc);
         }
         if (st) return st;
         st = c->alloc(&dinv, sizeof(double) * (size_t)Bc * (NB / TB) * TB * TB);
-        if (st) { c->release(Lbuf); return st; }
+        if (!st && g.lattice) st = c->alloc(&tab, tab_bytes * (size_t)Bc);
+        if (!st && g.lattice) st = c->alloc(&sig, sig_bytes * (size_t)Bc);
+        if (st) { c->release(Lbuf); c->release(dinv); c->release(tab); c->release(sig); return st; }
         const double nrows_aux = (double)g.naux;
         for (int b0 = 0; b0 < g.B; b0 += Bc) {
             const int bc = std::min(Bc, g.B - b0);
@@ -453,18 +540,59 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
             p.y0 = j->y0 + (g.y_shared ? 0 : (int64_t)b0 * g.n0);
             p.logdet = j->logdet + b0;
             p.info = j->info + b0;
+            p.tab = (double *)tab;
+            p.sig = (double *)sig;
+            p.qpts = j->qpts;
+            if (g.lattice)
+                tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
             const double fill_elems =
                 (double)bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0);
             tm.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, s); });
+            // Block columns in pairs: a FAT step finishes column jj and pre-accumulates column
+            // jj+1 (and the diagonal tile of jj+2) from the same streamed rows; the THIN step that
+            // follows only adds k in [64 (jj-1), 64 jj).  See chol_col_kernel.
+            bool ahead_pending = false;
             for (int jj = 0; jj < g.nb0; ++jj) {
+                const bool fat = (jj % 2 == 0) && (jj + 1 < g.nb0);
+                const bool thin = (jj % 2 == 1);
+                const int mode = fat ? COL_FAT : (thin ? COL_THIN : COL_FULL);
+                const int ahead = (fat && jj + 2 < g.nb0) ? 1 : 0;
+                const int k0_col = thin ? (jj - 1) * NB : 0;
+                // diag tile (jj,jj): odd jj pre-accumulated over k < 64 (jj-1) by the fat step
+                // jj-1; even jj >= 2 pre-accumulated over k < 64 (jj-2) by its diag-ahead tile
+                const int k0_diag = thin ? (jj - 1) * NB : (jj >= 2 ? (jj - 2) * NB : 0);
                 const double k = (double)jj * NB;
-                tm.run(1, bc * ((double)NB * NB * k + (double)NB * NB * NB / 3.0),
-                       bc * 8.0 * (NB * k + 2.0 * NB * NB),
-                       [&] { launch_chol_diag(g, p, bc, jj, sp, s); });
+                const double kd = k - k0_diag;
+                // the diag-ahead tile (jj, jj) was launched on the side stream at step jj-2, beside
+                // diag(jj-1) / col(jj-1); chol_diag(jj) is its only consumer
+                if (ahead_pending && (jj % 2 == 0)) {
+                    (void)hipStreamWaitEvent(s, c->ev_join, 0);
+                    ahead_pending = false;
+                }
+                tm.run(1, bc * ((double)NB * NB * kd + (double)NB * NB * NB / 3.0),
+                       bc * 8.0 * (NB * kd + 2.0 * NB * NB),
+                       [&] { launch_chol_diag(g, p, bc, jj, k0_diag, s); });
                 const double rows = (double)(g.n0 - (jj + 1) * NB) + nrows_aux;
-                tm.run(0, bc * rows * (2.0 * NB * k + (double)NB * NB),
-                       bc * 8.0 * (rows * k + NB * k + 2.0 * rows * NB),
-                       [&] { launch_chol_col(g, p, bc, jj, sp, s); });
+                const double kc = k - k0_col;
+                double fl = rows * (2.0 * NB * kc + (double)NB * NB);
+                double by = 8.0 * (rows * kc + NB * kc + 2.0 * rows * NB);
+                if (fat) {  // + column jj+1 partial sums from the same rows
+                    fl += rows * 2.0 * NB * k;
+                    by += 8.0 * (NB * k + 2.0 * rows * NB);
+                }
+                tm.run(0, bc * fl, bc * by,
+                       [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, ahead, s); });
+                if (ahead && jj > 0) {
+                    (void)hipEventRecord(c->ev_fork, s);
+                    (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
+                    launch_diag_ahead(g, p, bc, jj, c->side);
+                    (void)hipEventRecord(c->ev_join, c->side);
+                    ahead_pending = true;
+                }
+            }
+            if (ahead_pending) {
+                (void)hipStreamWaitEvent(s, c->ev_join, 0);
+                ahead_pending = false;
             }
             tm.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0, [&] {
                 launch_gram(g, (const double *)Lbuf, j->G + (int64_t)b0 * g.naux * g.naux, bc, s);
@@ -491,6 +619,8 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     tm.resolve(c->prof);
     c->release(Lbuf);
     c->release(dinv);
+    c->release(tab);
+    c->release(sig);
     if (err != hipSuccess) return (ngp_status)err;
     j->ran = true;
     return NGP_OK;
@@ -780,8 +910,11 @@ extern "C" ngp_status ngp_microbench_hbm(ngp_ctx *c, int64_t bytes, double *writ
     return NGP_OK;
 }
 
-// D = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 using the operand maps the kernels
-// assume; the caller compares with A @ B (asymmetric data) — tests/test_gpu_parity.py.
+// D[0:256]   = A(16x4) B(4x16) through one v_mfma_f64_16x16x4_f64 using the operand maps the
+//              kernels assume
+// D[256:512] = the same product through four DPP-rotated v_mfma_f64_4x4x4_4b_f64 + the gather back
+//              to the 16x16x4 C/D layout (the fast path of the k-loops)
+// The caller compares both with A @ B on asymmetric data — tests/test_gpu_parity.py.
 extern "C" ngp_status ngp_selftest_mfma_layout(ngp_ctx *c, const double *A, const double *Bm,
                                                double *D) {
     if (!c || !A || !Bm || !D) return NGP_ERR_ARG;
@@ -790,7 +923,7 @@ extern "C" ngp_status ngp_selftest_mfma_layout(ngp_ctx *c, const double *A, cons
     void *da = nullptr, *db = nullptr, *dd = nullptr;
     ngp_status st;
     if ((st = c->alloc(&da, 64 * 8)) || (st = c->alloc(&db, 64 * 8)) ||
-        (st = c->alloc(&dd, 256 * 8))) {
+        (st = c->alloc(&dd, 512 * 8))) {
         c->release(da); c->release(db); c->release(dd);
         return st;
     }
@@ -798,7 +931,7 @@ extern "C" ngp_status ngp_selftest_mfma_layout(ngp_ctx *c, const double *A, cons
     if (e == hipSuccess) e = hipMemcpyAsync(db, Bm, 64 * 8, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         launch_mfma_layout_probe((const double *)da, (const double *)db, (double *)dd, c->stream);
-        e = hipMemcpyAsync(D, dd, 256 * 8, hipMemcpyDeviceToHost, c->stream);
+        e = hipMemcpyAsync(D, dd, 512 * 8, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     c->release(da); c->release(db); c->release(dd);

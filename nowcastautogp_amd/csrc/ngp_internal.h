@@ -23,6 +23,7 @@ struct DevProgram {
     int32_t n_params;
     double  noise;               // observation-noise variance (jitter is in the spec)
     uint8_t ops[NGP_MAX_OPS];
+    uint8_t slot[NGP_MAX_OPS];   // per op: table slot (stationary leaf) or sigmoid slot (ChangePoint)
     double  params[NGP_MAX_PARAMS];
 };
 static_assert(sizeof(DevProgram) % 8 == 0, "DevProgram is copied as 8-byte words");
@@ -46,6 +47,13 @@ struct JobGeom {
     int32_t d;         // nowcast points per scenario
     int32_t noise_on_new;
     int32_t y_shared;  // 1: one base y / ya for all items
+    int32_t lattice;   // 1: all times sit on a lattice t = tmin + q h  -> table-driven fill
+    int32_t R;         // lattice table length (max |q_i - q_j| + 1)
+    int32_t npts;      // n0 + da + m points that carry a time
+    int32_t maxstat;   // stationary-leaf table slots per item
+    int32_t maxcp;     // ChangePoint sigmoid slots per item
+    int32_t pad0;
+    double  h;         // lattice step
     int64_t ld;        // row stride of the factor storage (= n0)
     int64_t item_stride;  // elements per item in the factor storage
 };
@@ -59,6 +67,9 @@ struct ChunkPtrs {
     const double *y0;     // [Bc or 1][n0] (already offset to the chunk when per item)
     double       *logdet; // [Bc]
     int32_t      *info;   // [Bc]
+    double       *tab;    // [Bc][maxstat][R]   stationary-leaf values by lattice distance
+    double       *sig;    // [Bc][maxcp][npts]  ChangePoint sigmoids by point
+    const int32_t *qpts;  // [npts] lattice coordinate of every point (t0 then taux)
 };
 
 struct EpiPtrs {
@@ -78,11 +89,13 @@ struct EpiPtrs {
 };
 
 // ---- launchers implemented in ngp_kernels.hip ------------------------------------------
+void launch_tables(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s);
 void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s);
-void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, const DevSpec &sp,
-                      hipStream_t s);
-void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, const DevSpec &sp,
-                     hipStream_t s);
+void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int k0, hipStream_t s);
+enum { COL_FULL = 0, COL_FAT = 1, COL_THIN = 2 };
+void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mode, int k0,
+                     int ahead, hipStream_t s);
+void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s);
 void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipStream_t s);
 void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2,

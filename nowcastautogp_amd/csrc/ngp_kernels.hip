@@ -25,6 +25,8 @@
 //   D: lane l, register r holds D[m = (l>>4) + 4 r][n = l&15]
 // so a D-layout tile is directly the B operand of a following product that sums over its row
 // index (register r <-> k-slot), which is what keeps the triangular solve in registers.
+#include <cstdlib>
+
 #include "ngp_internal.h"
 
 namespace ngp {
@@ -34,6 +36,85 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// The fast fp64 matrix path.  Measured on MI355X (profiles/r01/ubench_mfma_f64.log):
+//   v_mfma_f64_16x16x4_f64   ~100 cycles per SIMD slot (>=2 waves/SIMD)  -> 49.5 TFLOP/s ceiling
+//   v_mfma_f64_4x4x4_4b_f64   16.5 cycles for 512 flop, one wave suffices -> 75 TFLOP/s
+// The 4x4x4 form takes the SAME operand registers as the 16x16x4 form (A lane = m + 16 k,
+// B lane = n + 16 k) but produces only the four diagonal 4x4 blocks of the 16x16 product
+// (probed: D lane n' + 16 i = D[m = 4 (n'>>2) + i][n'], cbsz/abid ignored for f64).  Rotating the
+// B operand left by 4 r lanes inside each 16-lane row (DPP row_ror:16-4r; probed:
+// row_ror:n is dst[i] = src[(i - n) mod 16]) makes instruction r produce block-diagonal r:
+//     acc[r] lane (n', i)  =  D[m = 4 (n'>>2) + i][n = (n' + 4 r) mod 16]
+// so four of them (66 cycles) equal one 16x16x4 MFMA (100-138 cycles).  to_d16() gathers the
+// four accumulators back into the 16x16x4 C/D register layout with bank-masked DPP moves, so
+// everything downstream of the k-loop is unchanged.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_f64(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xF,
+                                               BANK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xF,
+                                               BANK, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int ROW_ROR4 = 0x124, ROW_ROR8 = 0x128, ROW_ROR12 = 0x12C;
+
+struct Rot4 {  // b and its three left-rotations by 4, 8, 12 lanes within each 16-lane row
+    double r0, r1, r2, r3;
+};
+__device__ __forceinline__ Rot4 rot4(double b) {
+    Rot4 o;
+    o.r0 = b;
+    o.r1 = dpp_f64<ROW_ROR12, 0xF>(b, b);
+    o.r2 = dpp_f64<ROW_ROR8, 0xF>(b, b);
+    o.r3 = dpp_f64<ROW_ROR4, 0xF>(b, b);
+    return o;
+}
+// one 16x16x4 product as four 4x4x4 MFMAs
+__device__ __forceinline__ void mfma16_as_4(double (&acc)[4], double a, const Rot4 &b) {
+    acc[0] = mfma4(a, b.r0, acc[0]);
+    acc[1] = mfma4(a, b.r1, acc[1]);
+    acc[2] = mfma4(a, b.r2, acc[2]);
+    acc[3] = mfma4(a, b.r3, acc[3]);
+}
+// four block-diagonal accumulators -> the 16x16x4 C/D layout (reg s, lane (n, q): D[q + 4s][n])
+__device__ __forceinline__ f64x4 to_d16(const double (&c)[4]) {
+    f64x4 o;
+    {
+        double x = c[0];
+        x = dpp_f64<ROW_ROR4, 0x2>(x, c[1]);
+        x = dpp_f64<ROW_ROR8, 0x4>(x, c[2]);
+        x = dpp_f64<ROW_ROR12, 0x8>(x, c[3]);
+        o[0] = x;
+    }
+    {
+        double x = c[0];
+        x = dpp_f64<ROW_ROR4, 0x4>(x, c[1]);
+        x = dpp_f64<ROW_ROR8, 0x8>(x, c[2]);
+        x = dpp_f64<ROW_ROR12, 0x1>(x, c[3]);
+        o[1] = x;
+    }
+    {
+        double x = c[0];
+        x = dpp_f64<ROW_ROR4, 0x8>(x, c[1]);
+        x = dpp_f64<ROW_ROR8, 0x1>(x, c[2]);
+        x = dpp_f64<ROW_ROR12, 0x2>(x, c[3]);
+        o[2] = x;
+    }
+    {
+        double x = c[0];
+        x = dpp_f64<ROW_ROR4, 0x1>(x, c[1]);
+        x = dpp_f64<ROW_ROR8, 0x2>(x, c[2]);
+        x = dpp_f64<ROW_ROR12, 0x4>(x, c[3]);
+        o[3] = x;
+    }
+    return o;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -147,36 +228,209 @@ __global__ __launch_bounds__(256) void fill_kernel(JobGeom g, ChunkPtrs p, int n
         c = a % g.nb0;
         aux = true;
     }
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col = c * NB + tx;
-    const double t2 = p.t0[col];
+    // thread = (column pair tx, 8-row group ty): two adjacent columns per thread -> 16-byte stores
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = c * NB + 2 * tx;
+    const double t2a = p.t0[col], t2b = p.t0[col + 1];
     const double diag = P.noise + sp.jitter;
     double *Lit = p.L + (long)item * g.item_stride;
     const int naux_t = g.da + g.m;
     const double *y0 = p.y0 + (g.y_shared ? 0 : (long)item * g.n0);
-    for (int rr = 0; rr < 16; ++rr) {
-        const int lr = ty * 16 + rr;
-        double v;
+    for (int rr = 0; rr < 8; ++rr) {
+        const int lr = ty * 8 + rr;
+        f64x2 v;
         long row;
         if (!aux) {
             row = (long)r * NB + lr;
-            v = keval(P, sp, p.t0[row], t2);
-            if (row == col) v += diag;
+            const double t1 = p.t0[row];
+            v.x = keval(P, sp, t1, t2a);
+            v.y = keval(P, sp, t1, t2b);
+            if (row == col) v.x += diag;
+            if (row == col + 1) v.y += diag;
         } else {
             const int ar = r * NB + lr;
             row = (long)g.n0 + ar;
-            if (ar < naux_t) v = keval(P, sp, p.taux[ar], t2);
-            else if (ar == naux_t) v = y0[col];
-            else v = 0.0;
+            if (ar < naux_t) {
+                v.x = keval(P, sp, p.taux[ar], t2a);
+                v.y = keval(P, sp, p.taux[ar], t2b);
+            } else if (ar == naux_t) {
+                v.x = y0[col];
+                v.y = y0[col + 1];
+            } else {
+                v.x = 0.0;
+                v.y = 0.0;
+            }
         }
-        Lit[row * g.ld + col] = v;
+        *reinterpret_cast<f64x2 *>(Lit + row * g.ld + col) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// table-driven fill.  Dates are integer days, so after AutoGP's [0,1] rescale every time sits on
+// a lattice t = tmin + q h.  Every transcendental of the kernel grammar is then a function of
+// either the integer distance |q_i - q_j| (SquaredExponential / GammaExponential / Periodic
+// leaves) or of a single point (ChangePoint sigmoids): O(n) evaluations per leaf instead of
+// O(n^2).  tables_kernel evaluates them once per item; fill_lattice_kernel is then pure
+// lookups + FMAs and runs at the HBM-write rate.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tables_kernel(JobGeom g, ChunkPtrs p, DevSpec sp) {
+    __shared__ DevProgram P;
+    const int item = blockIdx.x;
+    load_program(&P, p.progs + item);
+    __syncthreads();
+    double *tab = p.tab + (long)item * g.maxstat * g.R;
+    double *sig = p.sig + (long)item * g.maxcp * g.npts;
+    int pi = 0;
+    for (int i = 0; i < P.n_ops; ++i) {
+        const int op = __builtin_amdgcn_readfirstlane((int)P.ops[i]);
+        const int slot = __builtin_amdgcn_readfirstlane((int)P.slot[i]);
+        if (op == NGP_OP_SQEXP) {
+            const double l = P.params[pi], a = P.params[pi + 1];
+            const double den = sp.se_form ? l : l * l;
+            for (int k = threadIdx.x; k < g.R; k += 256) {
+                const double d = k * g.h;
+                tab[(long)slot * g.R + k] = a * exp(-0.5 * d * d / den);
+            }
+            pi += 2;
+        } else if (op == NGP_OP_GAMMAEXP) {
+            const double l = P.params[pi], gam = P.params[pi + 1], a = P.params[pi + 2];
+            for (int k = threadIdx.x; k < g.R; k += 256)
+                tab[(long)slot * g.R + k] = a * exp(-pow(k * g.h / l, gam));
+            pi += 3;
+        } else if (op == NGP_OP_PERIODIC) {
+            const double l = P.params[pi], per = P.params[pi + 1], a = P.params[pi + 2];
+            const double c = sp.periodic_form ? 2.0 / l : 2.0 / (l * l);
+            for (int k = threadIdx.x; k < g.R; k += 256) {
+                const double sn = sin(M_PI * (k * g.h) / per);
+                tab[(long)slot * g.R + k] = a * exp(-c * sn * sn);
+            }
+            pi += 3;
+        } else if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
+            const double loc = P.params[pi], sc = P.params[pi + 1];
+            for (int pt = threadIdx.x; pt < g.npts; pt += 256) {
+                const double t = pt < g.n0 ? p.t0[pt] : p.taux[pt - g.n0];
+                sig[(long)slot * g.npts + pt] = cp_sigma(sp.cp_form, t, loc, sc);
+            }
+            pi += 2;
+        } else if (op == NGP_OP_CONSTANT) {
+            pi += 1;
+        } else if (op == NGP_OP_LINEAR) {
+            pi += 3;
+        }
+    }
+}
+
+__device__ __forceinline__ double keval_lattice(const DevProgram &P, const double *tab,
+                                                const double *sig, int R, int npts, double t1,
+                                                double t2, int dq, int pt1, int pt2) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+    int pi = 0;
+    const int nops = P.n_ops;
+    for (int i = 0; i < nops; ++i) {
+        const int op = __builtin_amdgcn_readfirstlane((int)P.ops[i]);
+        if (op < NGP_OP_PLUS) {
+            double v;
+            if (op == NGP_OP_CONSTANT) {
+                v = P.params[pi];
+                pi += 1;
+            } else if (op == NGP_OP_LINEAR) {
+                const double c = P.params[pi];
+                v = P.params[pi + 1] + P.params[pi + 2] * (t1 - c) * (t2 - c);
+                pi += 3;
+            } else {
+                const int slot = __builtin_amdgcn_readfirstlane((int)P.slot[i]);
+                v = tab[(long)slot * R + dq];
+                pi += (op == NGP_OP_SQEXP) ? 2 : 3;
+            }
+            s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+        } else {
+            double v;
+            if (op == NGP_OP_PLUS) {
+                v = s1 + s0;
+            } else if (op == NGP_OP_TIMES) {
+                v = s1 * s0;
+            } else {
+                const int slot = __builtin_amdgcn_readfirstlane((int)P.slot[i]);
+                const double kl = (op == NGP_OP_CHANGEPOINT) ? s1 : s0;
+                const double kr = (op == NGP_OP_CHANGEPOINT) ? s0 : s1;
+                const double g1 = sig[(long)slot * npts + pt1];
+                const double g2 = sig[(long)slot * npts + pt2];
+                v = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+                pi += 2;
+            }
+            s0 = v; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+        }
+    }
+    return s0;
+}
+
+__global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs p, int ntri,
+                                                           DevSpec sp) {
+    __shared__ DevProgram P;
+    const int item = blockIdx.y;
+    load_program(&P, p.progs + item);
+    __syncthreads();
+    const int tile = blockIdx.x;
+    int r, c;
+    bool aux = false;
+    if (tile < ntri) {
+        r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+        while (r * (r + 1) / 2 > tile) --r;
+        c = tile - r * (r + 1) / 2;
+    } else {
+        const int a = tile - ntri;
+        r = a / g.nb0;
+        c = a % g.nb0;
+        aux = true;
+    }
+    // thread = (column pair tx, 8-row group ty): two adjacent columns per thread -> 16-byte stores
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = c * NB + 2 * tx;
+    const double t2a = p.t0[col], t2b = p.t0[col + 1];
+    const int q2a = p.qpts[col], q2b = p.qpts[col + 1];
+    const double diag = P.noise + sp.jitter;
+    double *Lit = p.L + (long)item * g.item_stride;
+    const double *tab = p.tab + (long)item * g.maxstat * g.R;
+    const double *sig = p.sig + (long)item * g.maxcp * g.npts;
+    const int naux_t = g.da + g.m;
+    const double *y0 = p.y0 + (g.y_shared ? 0 : (long)item * g.n0);
+    for (int rr = 0; rr < 8; ++rr) {
+        const int lr = ty * 8 + rr;
+        f64x2 v;
+        long row;
+        if (!aux) {
+            row = (long)r * NB + lr;
+            const int q1 = p.qpts[row];
+            const double t1 = p.t0[row];
+            v.x = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2a, abs(q1 - q2a), (int)row, col);
+            v.y = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2b, abs(q1 - q2b), (int)row, col + 1);
+            if (row == col) v.x += diag;
+            if (row == col + 1) v.y += diag;
+        } else {
+            const int ar = r * NB + lr;
+            row = (long)g.n0 + ar;
+            if (ar < naux_t) {
+                const int q1 = p.qpts[g.n0 + ar];
+                const double t1 = p.taux[ar];
+                v.x = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2a, abs(q1 - q2a), g.n0 + ar, col);
+                v.y = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2b, abs(q1 - q2b), g.n0 + ar, col + 1);
+            } else if (ar == naux_t) {
+                v.x = y0[col];
+                v.y = y0[col + 1];
+            } else {
+                v.x = 0.0;
+                v.y = 0.0;
+            }
+        }
+        *reinterpret_cast<f64x2 *>(Lit + row * g.ld + col) = v;
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // chol_diag: factor the 64x64 diagonal block of block column j
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, int j) {
+__global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, int j, int k0) {
     __shared__ double At[NB][NB + 1];
     __shared__ double Lt[NB][NB + 1];
     __shared__ double logs[NB];
@@ -197,14 +451,16 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
     // ---- C_jj = K_jj - L_j L_j'   (each wave one 32x32 quadrant; the strictly upper one is
     //      never read by the factorisation and is skipped)
     if (!(wr == 0 && wc == 1)) {
-        f64x4 acc[2][2];
+        double acc4[2][2][4];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = (f64x4){0, 0, 0, 0};
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
         const double *pa = Lj + (long)(32 * wr + r16) * ld + 2 * q;
         const double *pb = Lj + (long)(32 * wc + r16) * ld + 2 * q;
-        for (int kc = 0; kc < kmax; kc += 16) {
+        for (int kc = k0; kc < kmax; kc += 16) {
             double a[2][4], b[2][4];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -218,11 +474,17 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int nt = 0; nt < 2; ++nt) {
+                    const Rot4 br = rot4(b[nt][s]);
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[mt][nt] = mfma64(a[mt][s], b[nt][s], acc[mt][nt]);
+                    for (int mt = 0; mt < 2; ++mt) mfma16_as_4(acc4[mt][nt], a[mt][s], br);
+                }
         }
+        f64x4 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = to_d16(acc4[a][b]);
         // D layout: register s of acc[mt][nt] is S[M = 32wr+16mt+q+4s][N = 32wc+16nt+r16]
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -286,85 +548,118 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
 }
 
 // ---------------------------------------------------------------------------------------
-// chol_col: every row tile below the diagonal of block column j (and every aux tile):
-//           C_rj -= L_r,0:k L_j,0:k'   then   L_rj = C_rj L_jj^-T
-// One 64x64 tile per wave, 4 tiles per workgroup; the transposed tile C' is accumulated so the
+// chol_col: every row tile below the diagonal of block column j (and every aux tile).
+//
+//   C_rj -= L_r,[k0,k1) L_j,[k0,k1)'    then    L_rj = C_rj L_jj^-T
+//
+// One 64-row tile per wave, 4 tiles per workgroup.  The transposed tile C' is accumulated so the
 // solve can consume the accumulators as MFMA B operands in place.
+//
+// HBM traffic of a left-looking factorisation is one pass over all previous columns of every row
+// tile per block column; at the 4x4x4 MFMA rate a 64-wide block column needs ~4.7 TB/s of that
+// (measured: the kernel turned bandwidth-bound).  So block columns are processed in pairs with
+// register-level reuse of the streamed rows:
+//   FAT  step (j even):  accumulate column j over k < 64 j AND pre-accumulate column j+1 over the
+//                        same k from the same B-operand registers (64 x 128 per wave, 256
+//                        accumulator VGPRs, one wave per SIMD); column j is finished (solve +
+//                        store), column j+1's partial sum is subtracted from K in place.
+//   THIN step (j odd):   only k in [64 (j-1), 64 j) is left.
+//   FULL step:           single column over all k (last column of an odd count).
+// The fat launch also pre-accumulates the diagonal tile (j+2, j+2) over k < 64 j ("diag-ahead"
+// tile), so chol_diag never runs a long k-loop on one workgroup.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_col_kernel(JobGeom g, ChunkPtrs p, int Bc, int j,
-                                                       int groups, int nmain, int ntiles) {
-    const int wg = blockIdx.x;
-    const int xcd = wg & 7, idx = wg >> 3;   // blocks b and b+8 share an XCD (speed only)
-    const int item = (idx / groups) * 8 + xcd;
-    const int grp = idx % groups;
-    if (item >= Bc) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = grp * 4 + wave;
-    if (tile >= ntiles) return;
+// 8 k-values of NF 16-row fragments: lane (r16, q) holds rows 16u + r16, k = kc + 2q, 2q + 1
+template <int NF>
+struct Frag8 {
+    f64x2 v[NF];
+};
+template <int NF>
+__device__ __forceinline__ void load_frag8(Frag8<NF> &f, const double *p, long ld) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) f.v[u] = *reinterpret_cast<const f64x2 *>(p + (long)u * 16 * ld);
+}
+template <int NA>
+__device__ __forceinline__ void mfma_frag8(double (&acc)[NA][4][4], const Frag8<NA> &a,
+                                           const Frag8<4> &b) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const Rot4 br = rot4(b.v[it].x);
+#pragma unroll
+        for (int jt = 0; jt < NA; ++jt) mfma16_as_4(acc[jt][it], a.v[jt].x, br);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const Rot4 br = rot4(b.v[it].y);
+#pragma unroll
+        for (int jt = 0; jt < NA; ++jt) mfma16_as_4(acc[jt][it], a.v[jt].y, br);
+    }
+}
 
-    const long ld = g.ld;
-    double *Lit = p.L + (long)item * g.item_stride;
-    const double *Lj = Lit + (long)j * NB * ld;
-    const long rowbase = (tile < nmain) ? (long)(j + 1 + tile) * NB
-                                        : (long)g.n0 + (long)(tile - nmain) * NB;
-    double *Lr = Lit + rowbase * ld;
-    const int kmax = j * NB;
-    const int r16 = lane & 15, q = lane >> 4;
+// acc[jt][it] += sum_{k in [k0,k1)} A[16jt + m][k] B[16it + n][k]; A rows are NA*16 consecutive
+// rows at pa (lane offset applied by the caller), B rows the wave's 64 tile rows at pb.
+// k1 - k0 is a multiple of 16: two 8-deep operand stages ping-pong.
+template <int NA>
+__device__ __forceinline__ void gemm_rows(double (&acc)[NA][4][4], const double *pa,
+                                          const double *pb, long ld, int k0, int k1) {
+    if (k1 <= k0) return;
+    Frag8<NA> a0, a1;
+    Frag8<4> b0, b1;
+    load_frag8(a0, pa + k0, ld);
+    load_frag8(b0, pb + k0, ld);
+    for (int kc = k0; kc < k1; kc += 16) {
+        load_frag8(a1, pa + kc + 8, ld);
+        load_frag8(b1, pb + kc + 8, ld);
+        mfma_frag8(acc, a0, b0);
+        if (kc + 16 < k1) {
+            load_frag8(a0, pa + kc + 16, ld);
+            load_frag8(b0, pb + kc + 16, ld);
+        }
+        mfma_frag8(acc, a1, b1);
+    }
+}
 
+// tile[i][c0 + jj] -= S'[jj][i] for a 64 x 64 tile held as four-by-four block-diagonal accumulators
+__device__ __forceinline__ void subtract_in_place(double *rows, long ld, int c0,
+                                                  const double (*acc4)[4][4], int r16, int q) {
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const f64x4 d = to_d16(acc4[jt][it]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double *e = rows + (long)(16 * it + r16) * ld + c0 + 16 * jt + q + 4 * s;
+                *e -= d[s];
+            }
+        }
+}
+
+// Finish column j of one tile: C' = K' - S', X' = L_jj^-1 C' by 16-row block substitution
+//   X'_ct = Dinv_ct (C'_ct - sum_{jt<ct} L_jj[ct][jt] X'_jt)
+// on the 16x16x4 C/D layout (a D tile is directly the B operand of a product that sums over its
+// row index), then store L_rj.  The K tile is pulled in one 16-column slab per ct.
+__device__ __forceinline__ void solve_and_store(const double (*acc4)[4][4], double *Lr,
+                                                const double *Lj, const double *dinv, long ld,
+                                                int kmax, int r16, int q) {
     f64x4 acc[4][4];  // acc[jt][it]: S'[jj = 16jt + q + 4s][i = 16it + r16]
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f64x4){0, 0, 0, 0};
-
-    const double *pa = Lj + (long)r16 * ld + 2 * q;  // A operand: rows of block j (M = jj)
-    const double *pb = Lr + (long)r16 * ld + 2 * q;  // B operand: rows of this tile (N = i)
-    for (int kc = 0; kc < kmax; kc += 16) {
-        double a[4][4], b[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f64x2 alo = *reinterpret_cast<const f64x2 *>(pa + (long)u * 16 * ld + kc);
-            const f64x2 ahi = *reinterpret_cast<const f64x2 *>(pa + (long)u * 16 * ld + kc + 8);
-            const f64x2 blo = *reinterpret_cast<const f64x2 *>(pb + (long)u * 16 * ld + kc);
-            const f64x2 bhi = *reinterpret_cast<const f64x2 *>(pb + (long)u * 16 * ld + kc + 8);
-            a[u][0] = alo.x; a[u][1] = alo.y; a[u][2] = ahi.x; a[u][3] = ahi.y;
-            b[u][0] = blo.x; b[u][1] = blo.y; b[u][2] = bhi.x; b[u][3] = bhi.y;
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    acc[jt][it] = mfma64(a[jt][s], b[it][s], acc[jt][it]);
-    }
-
-    // C' = K' - S'   (K_rj was put in place by fill_kernel)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int jj = 16 * jt + q + 4 * s, i = 16 * it + r16;
-                acc[jt][it][s] = Lr[(long)i * ld + kmax + jj] - acc[jt][it][s];
-            }
-
-    // X' = L_jj^-1 C' by 16-row block substitution:
-    //   X'_ct = Dinv_ct (C'_ct - sum_{jt<ct} L_jj[ct][jt] X'_jt),  X'_ct overwrites acc[ct]
-    const double *dinv = p.dinv + (long)item * (NB / TB) * (TB * TB);
+        for (int b = 0; b < 4; ++b) acc[a][b] = to_d16(acc4[a][b]);
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
         f64x4 tmp[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) tmp[it] = acc[ct][it];
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                tmp[it][s] = Lr[(long)(16 * it + r16) * ld + kmax + 16 * ct + q + 4 * s] -
+                             acc[ct][it][s];
 #pragma unroll
         for (int jt = 0; jt < ct; ++jt) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const double a =
-                    -Lj[(long)(16 * ct + r16) * ld + kmax + 16 * jt + q + 4 * s];
+                const double a = -Lj[(long)(16 * ct + r16) * ld + kmax + 16 * jt + q + 4 * s];
 #pragma unroll
                 for (int it = 0; it < 4; ++it) tmp[it] = mfma64(a, acc[jt][it][s], tmp[it]);
             }
@@ -377,6 +672,7 @@ __global__ __launch_bounds__(256) void chol_col_kernel(JobGeom g, ChunkPtrs p, i
 #pragma unroll
             for (int it = 0; it < 4; ++it) acc[ct][it] = mfma64(a, tmp[it][s], acc[ct][it]);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     // store L_rj: X'[c = 16ct + q + 4s][i = 16it + r16] -> L_r[i][kmax + c]
 #pragma unroll
@@ -386,6 +682,252 @@ __global__ __launch_bounds__(256) void chol_col_kernel(JobGeom g, ChunkPtrs p, i
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 Lr[(long)(16 * it + r16) * ld + kmax + 16 * ct + q + 4 * s] = acc[ct][it][s];
+}
+
+struct ColStep {
+    int j;        // block column being finished
+    int k0;       // first k not yet accumulated into column j
+    int nmain;    // main row tiles below the diagonal (r = j+1 ...)
+    int ntiles;   // nmain + aux tiles (+ 1 diag-ahead tile when fat && ahead)
+    int groups;   // workgroups per item
+    int ahead;    // fat only: 1 if the tile (j+2, j+2) is pre-accumulated by an extra tile
+    int dbg;      // timing ablations (results wrong when != 0): 1 no restaging, 2 no barriers,
+                  // 4 no epilogue; set from the NGP_ABLATE environment variable, never by the API
+};
+
+// FAT launches pair the waves of a workgroup: waves 2t and 2t+1 take the SAME 64 tile rows (the
+// second fetch of every streamed line hits L1/L2, so HBM sees the rows once per two block
+// columns); the even wave finishes column j, the odd wave pre-accumulates column j+1 and
+// subtracts it from K in place.  128 accumulator VGPRs per wave, two waves per SIMD.
+// (A 64 x 128 tile in one wave needs 256 accumulators; hipcc then splits them across the
+// AGPR/VGPR halves and moves them every iteration — measured 2x slower.)
+template <bool FAT>
+__global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p, int Bc,
+                                                          ColStep st) {
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7, idx = wg >> 3;   // blocks b and b+8 share an XCD (speed only)
+    const int item = (idx / st.groups) * 8 + xcd;
+    const int grp = idx % st.groups;
+    if (item >= Bc) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = grp * 4 + wave;
+    const int tile = FAT ? (slot >> 1) : slot;   // row tile
+    const int col = FAT ? (slot & 1) : 0;        // 0: column j, 1: column j+1 (partial)
+    if (tile >= st.ntiles) return;
+
+    const int j = st.j;
+    const long ld = g.ld;
+    double *Lit = p.L + (long)item * g.item_stride;
+    const int kmax = j * NB;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int naux_tiles = g.naux_pad / NB;
+
+    double acc4[4][4][4];  // [jt][it][r]: block-diagonal r of S' tile (jt, it), see mfma16_as_4
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
+
+    if (FAT && st.ahead && tile == st.nmain + naux_tiles) {
+        // diag-ahead: K_(j+2,j+2) -= L_(j+2),[0,kmax) L_(j+2),[0,kmax)'  (one wave of the pair)
+        if (col) return;
+        double *Ld = Lit + (long)(j + 2) * NB * ld;
+        const double *pd = Ld + (long)r16 * ld + 2 * q;
+        gemm_rows<4>(acc4, pd, pd, ld, 0, kmax);
+        subtract_in_place(Ld, ld, (j + 2) * NB, acc4, r16, q);
+        return;
+    }
+
+    const long rowbase = (tile < st.nmain) ? (long)(j + 1 + tile) * NB
+                                           : (long)g.n0 + (long)(tile - st.nmain) * NB;
+    double *Lr = Lit + rowbase * ld;
+    const double *Lj = Lit + (long)(j + col) * NB * ld;   // A operand: rows of block j (+1)
+    const double *pa = Lj + (long)r16 * ld + 2 * q;
+    const double *pb = Lr + (long)r16 * ld + 2 * q;        // B operand: rows of this tile
+    gemm_rows<4>(acc4, pa, pb, ld, st.k0, kmax);
+    if (FAT && col) {
+        subtract_in_place(Lr, ld, (j + 1) * NB, acc4, r16, q);   // column j+1, partial sum
+    } else {
+        const double *dinv = p.dinv + (long)item * (NB / TB) * (TB * TB);
+        solve_and_store(acc4, Lr, Lj, dinv, ld, kmax, r16, q);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// chol_col, LDS-staged form (the production path; the direct-load kernel above remains for the
+// single diag-ahead tile).  Same math and the same FAT / THIN / FULL schedule, different data
+// movement:
+//   * the workgroup loads each 16-deep k-chunk of its operand rows cooperatively with full-line
+//     global loads (8 rows x 128 B per wave-instruction instead of 16 half-lines), once, into a
+//     padded LDS tile (row stride 136 B: the 16 rows of a fragment land on distinct banks);
+//   * two LDS buffers, one barrier per chunk: chunk c+1 travels HBM -> registers while chunk c is
+//     multiplied, and is written to the other buffer after the MFMAs;
+//   * the three rotated copies of every B fragment that the 4x4x4 MFMA form needs come from LDS by
+//     address (row (n' + 4r) mod 16) instead of DPP moves: the k-loop is ds_read_b64 + MFMA only.
+//   FAT steps only (they carry all the long k-loops): A panel = rows of blocks j and j+1 (128),
+//   B = 2 row tiles (128); wave = (tile, column).  THIN / FULL steps use the direct-load kernel.
+// ---------------------------------------------------------------------------------------
+// bytes per staged row: 16 doubles + 8 B pad = 34 dwords.  hipcc fuses the k-adjacent operand reads
+// into ds_read2_b64 (banked mod 32 per 16-lane group): the 16 rows of a fragment then need a row
+// stride of 2*odd dwords to cover all 32 banks once (a 144-B stride measured 45 % conflict cycles).
+constexpr int LDS_ROWB = 136;
+constexpr int LDS_KC = 16;
+
+__global__ __launch_bounds__(256, 2) void chol_col_lds_kernel(JobGeom g, ChunkPtrs p, int Bc,
+                                                              ColStep st) {
+    constexpr int AROWS = 128, BROWS = 128, ROWS = AROWS + BROWS;
+    constexpr int STAGE = ROWS * LDS_ROWB;       // bytes per buffer
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7, idx = wg >> 3;       // blocks b and b+8 share an XCD (speed only)
+    const int item = (idx / st.groups) * 8 + xcd;
+    const int grp = idx % st.groups;
+    if (item >= Bc) return;                      // whole workgroup, before any barrier
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ltile = wave >> 1;                 // which of the workgroup's two row tiles
+    const int col = wave & 1;                    // 0: column j, 1: column j+1 (partial)
+    const int tile0 = grp * 2;
+    const int tile = tile0 + ltile;
+    const bool valid = tile < st.ntiles;
+
+    const int j = st.j;
+    const long ld = g.ld;
+    double *Lit = p.L + (long)item * g.item_stride;
+    const int kmax = j * NB;
+    const int r16 = lane & 15, q = lane >> 4;
+    auto tile_row0 = [&](int t) -> long {
+        if (t >= st.ntiles) t = st.ntiles - 1;   // out-of-range slot stages a valid tile, computes nothing
+        return (t < st.nmain) ? (long)(j + 1 + t) * NB : (long)g.n0 + (long)(t - st.nmain) * NB;
+    };
+    // ---- staging: thread -> (row tid>>3 (+32 per step), 16-B piece tid&7).  Buffer loads: one
+    //      descriptor for the item, ONE per-thread byte offset, everything else scalar
+    //      (region base, row step, k) — keeps the address arithmetic out of the VGPR file.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        Lit, 0, (int)(g.item_stride * (long)sizeof(double)), 0x00020000);
+    const unsigned offA = (unsigned)((long)j * NB * ld * 8);
+    const unsigned offB0 = (unsigned)(tile_row0(tile0) * ld * 8);
+    const unsigned offB1 = (unsigned)(tile_row0(tile0 + 1) * ld * 8);
+    const unsigned step32 = (unsigned)(32 * ld * 8);
+    const unsigned voff = (unsigned)(((tid >> 3) * ld + 2 * (tid & 7)) * 8);
+    const unsigned lwr = (unsigned)((tid >> 3) * LDS_ROWB + (tid & 7) * 16);
+    // ---- operand read addresses (bytes inside a stage)
+    const unsigned a_base = (unsigned)((64 * col + r16) * LDS_ROWB + q * 8);
+    unsigned b_base[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        b_base[r] = (unsigned)((AROWS + 64 * ltile + ((r16 + 4 * r) & 15)) * LDS_ROWB + q * 8);
+
+    double acc4[4][4][4];  // [jt][it][r]: block-diagonal r of S' tile (jt, it), see mfma16_as_4
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto gload = [&](f64x2 (&stg)[8], int k) {
+        const unsigned kb = (unsigned)k * 8u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, offA + i * step32 + kb, 0);
+            stg[i] = __builtin_bit_cast(f64x2, v);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, offB0 + i * step32 + kb, 0);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, offB1 + i * step32 + kb, 0);
+            stg[4 + i] = __builtin_bit_cast(f64x2, v0);
+            stg[6 + i] = __builtin_bit_cast(f64x2, v1);
+        }
+    };
+    auto lstore = [&](char *buf, const f64x2 (&stg)[8]) {   // rows are 8-B aligned only
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            double *d = reinterpret_cast<double *>(buf + lwr + i * 32 * LDS_ROWB);
+            d[0] = stg[i].x;
+            d[1] = stg[i].y;
+        }
+    };
+
+    const int nchunks = (kmax - st.k0) / LDS_KC;
+    if (nchunks > 0) {
+        f64x2 stg[8];
+        gload(stg, st.k0);
+        lstore(smem, stg);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const char *buf = smem + (c & 1) * STAGE;
+            if (c + 1 < nchunks && !(st.dbg & 1)) gload(stg, st.k0 + (c + 1) * LDS_KC);
+            const char *pa = buf + a_base;
+            const char *pb0 = buf + b_base[0], *pb1 = buf + b_base[1];
+            const char *pb2 = buf + b_base[2], *pb3 = buf + b_base[3];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                double a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    a[u] = *reinterpret_cast<const double *>(pa + u * 16 * LDS_ROWB + s * 32);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    Rot4 br;
+                    br.r0 = *reinterpret_cast<const double *>(pb0 + it * 16 * LDS_ROWB + s * 32);
+                    br.r1 = *reinterpret_cast<const double *>(pb1 + it * 16 * LDS_ROWB + s * 32);
+                    br.r2 = *reinterpret_cast<const double *>(pb2 + it * 16 * LDS_ROWB + s * 32);
+                    br.r3 = *reinterpret_cast<const double *>(pb3 + it * 16 * LDS_ROWB + s * 32);
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[jt], br);
+                }
+            }
+            if (c + 1 < nchunks && !(st.dbg & 1)) lstore(smem + ((c + 1) & 1) * STAGE, stg);
+            if (!(st.dbg & 2)) __syncthreads();
+        }
+    }
+    if (!valid) return;
+    if (st.dbg & 4) {   // keep the accumulators alive, skip the epilogue
+        double sum = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum += acc4[a][b][r];
+        if (sum == 1.2345e-300) p.logdet[item] = sum;
+        return;
+    }
+
+    double *Lr = Lit + tile_row0(tile) * ld;
+    const double *Lj = Lit + (long)(j + col) * NB * ld;
+    if (col) {
+        subtract_in_place(Lr, ld, (j + 1) * NB, acc4, r16, q);   // column j+1, partial sum
+    } else {
+        const double *dinv = p.dinv + (long)item * (NB / TB) * (TB * TB);
+        solve_and_store(acc4, Lr, Lj, dinv, ld, kmax, r16, q);
+    }
+}
+
+// diag-ahead: K_(j+2,j+2) -= L_(j+2),[0,kmax) L_(j+2),[0,kmax)' — one wave per item, next to the
+// fat launch (pre-accumulates the next-but-one diagonal tile so chol_diag's own k-loop is <= 128)
+__global__ __launch_bounds__(64, 2) void diag_ahead_kernel(JobGeom g, ChunkPtrs p, int j) {
+    const int item = blockIdx.x, lane = threadIdx.x & 63;
+    const long ld = g.ld;
+    double *Ld = p.L + (long)item * g.item_stride + (long)(j + 2) * NB * ld;
+    const int r16 = lane & 15, q = lane >> 4;
+    double acc4[4][4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
+    const double *pd = Ld + (long)r16 * ld + 2 * q;
+    gemm_rows<4>(acc4, pd, pd, ld, 0, j * NB);
+    subtract_in_place(Ld, ld, (j + 2) * NB, acc4, r16, q);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -569,6 +1111,17 @@ __global__ void mfma_layout_probe_kernel(const double *A, const double *Bm, doub
     for (int r = 0; r < 4; ++r) Dout[((l >> 4) + 4 * r) * 16 + (l & 15)] = d[r];
 }
 
+__global__ void mfma4_composite_probe_kernel(const double *A, const double *Bm, double *Dout) {
+    const int l = threadIdx.x;
+    const double a = A[(l & 15) * 4 + (l >> 4)];
+    const double b = Bm[(l >> 4) * 16 + (l & 15)];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    mfma16_as_4(acc, a, rot4(b));
+    const f64x4 d = to_d16(acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dout[((l >> 4) + 4 * r) * 16 + (l & 15)] = d[r];
+}
+
 __global__ __launch_bounds__(256) void stream_write_kernel(f64x2 *dst, long n2) {
     const f64x2 v = {1.0, 2.0};
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256)
@@ -582,27 +1135,51 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(f64x2 *dst, const f64x
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
+void launch_tables(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s) {
+    if (g.n0 == 0 || !g.lattice) return;
+    hipLaunchKernelGGL(tables_kernel, dim3(Bc), dim3(256), 0, s, g, p, sp);
+}
+
 void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s) {
     if (g.n0 == 0) return;
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
     const int ntiles = ntri + (g.naux_pad / NB) * g.nb0;
-    hipLaunchKernelGGL(fill_kernel, dim3(ntiles, Bc), dim3(256), 0, s, g, p, ntri, sp);
+    if (g.lattice)
+        hipLaunchKernelGGL(fill_lattice_kernel, dim3(ntiles, Bc), dim3(256), 0, s, g, p, ntri, sp);
+    else
+        hipLaunchKernelGGL(fill_kernel, dim3(ntiles, Bc), dim3(256), 0, s, g, p, ntri, sp);
 }
 
-void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, const DevSpec &,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(Bc), dim3(256), 0, s, g, p, j);
+void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int k0, hipStream_t s) {
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(Bc), dim3(256), 0, s, g, p, j, k0);
 }
 
-void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, const DevSpec &,
-                     hipStream_t s) {
-    const int nmain = g.nb0 - 1 - j;
-    const int ntiles = nmain + g.naux_pad / NB;
-    if (ntiles <= 0) return;
-    const int groups = (ntiles + 3) / 4;
+void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mode, int k0,
+                     int ahead, hipStream_t s) {
+    ColStep st{};
+    static const int dbg = getenv("NGP_ABLATE") ? atoi(getenv("NGP_ABLATE")) : 0;
+    st.dbg = dbg;
+    st.j = j;
+    st.k0 = k0;
+    st.nmain = g.nb0 - 1 - j;
+    st.ahead = 0;
+    st.ntiles = st.nmain + g.naux_pad / NB;
+    if (st.ntiles <= 0) return;
     const int bpad = (Bc + 7) / 8 * 8;
-    hipLaunchKernelGGL(chol_col_kernel, dim3(groups * bpad), dim3(256), 0, s, g, p, Bc, j, groups,
-                       nmain, ntiles);
+    if (mode == COL_FAT) {
+        st.groups = (st.ntiles + 1) / 2;
+        hipLaunchKernelGGL(chol_col_lds_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p, Bc,
+                           st);
+        (void)ahead;
+    } else {
+        st.groups = (st.ntiles + 3) / 4;
+        hipLaunchKernelGGL(chol_col_kernel<false>, dim3(st.groups * bpad), dim3(256), 0, s, g, p,
+                           Bc, st);
+    }
+}
+
+void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {
+    hipLaunchKernelGGL(diag_ahead_kernel, dim3(Bc), dim3(64), 0, s, g, p, j);
 }
 
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s) {
@@ -632,6 +1209,7 @@ void launch_mfma_bench_detail(unsigned long long *stamps, int iters, int blocks,
 }
 void launch_mfma_layout_probe(const double *A, const double *Bm, double *Dout, hipStream_t s) {
     hipLaunchKernelGGL(mfma_layout_probe_kernel, dim3(1), dim3(64), 0, s, A, Bm, Dout);
+    hipLaunchKernelGGL(mfma4_composite_probe_kernel, dim3(1), dim3(64), 0, s, A, Bm, Dout + 256);
 }
 void launch_stream_write(double *dst, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(stream_write_kernel, dim3(2048), dim3(256), 0, s,

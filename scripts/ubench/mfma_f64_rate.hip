@@ -24,6 +24,22 @@ __global__ __launch_bounds__(256) void k_mfma(unsigned long long *st, int iters)
 }
 
 template <int NACC>
+__global__ __launch_bounds__(256) void k_mfma4(unsigned long long *st, int iters) {
+    double c[NACC], a[NACC], b[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) { c[i] = 0; a[i] = 1.0 + 1e-9 * (threadIdx.x + i); b[i] = 1.0 - 1e-9 * (threadIdx.x + 3 * i); }
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it += NACC) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i], b[i], c[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) asm volatile("" ::"v"(c[i]));
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) { int w = blockIdx.x * 4 + (threadIdx.x >> 6); st[2 * w] = t1 - t0; st[2 * w + 1] = r1 - r0; }
+}
+
+template <int NACC>
 __global__ __launch_bounds__(256) void k_fma(unsigned long long *st, int iters) {
     double c[NACC];
     double a = 1.0 + 1e-9 * threadIdx.x, b = 1e-9 * threadIdx.x;
@@ -71,6 +87,10 @@ int main() {
         run("mfma", k_mfma<4>, 4, bpc, it, 2048);
         run("mfma", k_mfma<8>, 8, bpc, it, 2048);
         run("mfma", k_mfma<16>, 16, bpc, it, 2048);
+    }
+    for (int bpc : {1, 2, 4, 8}) {
+        run("mfma4x4", k_mfma4<4>, 4, bpc, it * 4, 512);
+        run("mfma4x4", k_mfma4<16>, 16, bpc, it * 4, 512);
     }
     for (int bpc : {1, 2, 4, 8}) {
         run("fma64", k_fma<8>, 8, bpc, it * 16, 128);

@@ -32,12 +32,13 @@ def test_mfma_f64_operand_maps(ctx):
     rng = np.random.default_rng(0)
     A = rng.integers(-4, 5, (16, 4)).astype(float)
     B = rng.integers(-4, 5, (4, 16)).astype(float)
-    assert np.array_equal(ctx.selftest_mfma_layout(A, B), A @ B)
+    for D in ctx.selftest_mfma_layout(A, B):     # 16x16x4 form, then 4 rotated 4x4x4 + gather
+        assert np.array_equal(D, A @ B)
     A = np.zeros((16, 4))
     A[:4, :4] = np.eye(4)
     B = np.arange(64, dtype=float).reshape(4, 16)
-    D = ctx.selftest_mfma_layout(A, B)
-    assert np.array_equal(D[:4], B) and not D[4:].any()
+    for D in ctx.selftest_mfma_layout(A, B):
+        assert np.array_equal(D[:4], B) and not D[4:].any()
 
 
 def test_cov_matches_golden(ctx, golden):
@@ -91,6 +92,35 @@ def test_logml_sizes_and_ragged_tails(ctx, n):
         assert i0 == 0 and info[b] == 0
         cond = np.linalg.cond(oracle_np.cov(prog, t, t, True))
         assert nerr(lm[b], ref) < tol(TOL_LOGML, cond), (n, b)
+
+
+@pytest.mark.parametrize("kind", ["irregular", "gaps", "weekly_days"])
+def test_time_grids_direct_and_lattice_fill(ctx, kind):
+    """irregular times take the direct-evaluation fill, lattice times (also with missing points,
+    and integer-day dates rescaled to [0,1]) take the table-driven fill; both must match."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    n = 200
+    if kind == "irregular":
+        t = np.sort(rng.uniform(0, 1, n))
+        t_new = np.array([1.01, 1.07, 1.2])
+    elif kind == "gaps":
+        q = np.sort(rng.choice(400, size=n, replace=False))
+        t = (q - q[0]) / (q[-1] - q[0])
+        t_new = 1.0 + np.array([3, 4, 9]) / (q[-1] - q[0])
+    else:
+        days = 7 * np.arange(n)                     # weekly dates as integer days
+        t = days / days[-1]
+        t_new = (days[-1] + 7 * np.arange(1, 4)) / days[-1]
+    y = np.sin(9 * t) + 0.1 * rng.standard_normal(n)
+    progs = make_ensemble(rng, 10, depth_cap=4)
+    mu, sg, lm, info = ctx.predict_batch(progs, t, y, t_new)
+    assert not info.any()
+    for b, prog in enumerate(progs):
+        cond = np.linalg.cond(oracle_np.cov(prog, t, t, True))
+        rmu, rsg, rlm, _ = oracle_np.predict(prog, t, y, t_new)
+        assert nerr(lm[b], rlm) < tol(TOL_LOGML, cond), (kind, b)
+        assert nerr(mu[b], rmu) < tol(TOL_PRED, cond), (kind, b)
+        assert nerr(sg[b], rsg) < tol(TOL_PRED, cond), (kind, b)
 
 
 def test_per_item_y_rows(ctx):
