@@ -498,23 +498,68 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
     }
     __syncthreads();
 
-    // ---- right-looking Cholesky of the 64x64 tile in LDS; one barrier per column: column k is
-    //      read-only during step k (scaled copies go to Lt), the trailing update writes j > k
-    const int tx = tid & 15, ty = tid >> 4;
-    for (int k = 0; k < NB; ++k) {
-        __syncthreads();
-        const double akk = At[k][k];
-        const double dk = sqrt(akk);
-        const double inv = 1.0 / dk;
-        if (tid == 0) {
-            if (!(akk > 0.0) && bad == 0) bad = k + 1;
-            Lt[k][k] = dk;
-            logs[k] = log(dk);
+    // ---- right-looking Cholesky of the 64x64 tile, register-blocked: thread (bi, bj) owns the 4x4
+    //      block rows 4bi.., cols 4bj..; per pivot only the (unscaled) pivot column travels through
+    //      LDS (double-buffered, one barrier per pivot), every thread rescales what it needs and
+    //      updates its 16 elements in registers.  Same operation order as the textbook loop:
+    //      a_ij -= (a_ik / sqrt(a_kk)) (a_jk / sqrt(a_kk)).
+    {
+        double(*colbuf)[NB] = reinterpret_cast<double(*)[NB]>(&Lt[0][0]);  // Lt is free until the end
+        const int bi = tid >> 4, bj = tid & 15;
+        double a[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[r][c] = At[4 * bi + r][4 * bj + c];
+        __syncthreads();   // everyone has its block: Lt may now be reused as the column buffer
+        for (int kb = 0; kb < NB / 4; ++kb) {
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                const int k = 4 * kb + kc;
+                double *cb = colbuf[k & 1];
+                if (bj == kb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cb[4 * bi + r] = a[r][kc];
+                }
+                __syncthreads();
+                const double akk = cb[k];
+                const double dk = sqrt(akk);
+                const double inv = 1.0 / dk;
+                if (tid == 0) {
+                    if (!(akk > 0.0) && bad == 0) bad = k + 1;
+                    logs[k] = log(dk);
+                }
+                double li[4], lj[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) li[r] = cb[4 * bi + r] * inv;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lj[c] = cb[4 * bj + c] * inv;
+                if (bj > kb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a[r][c] -= li[r] * lj[c];
+                } else if (bj == kb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c > kc) a[r][c] -= li[r] * lj[c];
+                        const int row = 4 * bi + r;
+                        a[r][kc] = row > k ? li[r] : (row == k ? dk : 0.0);   // column k of L
+                    }
+                }
+            }
         }
-        if (tid > k && tid < NB) Lt[tid][k] = At[tid][k] * inv;
-        for (int i = k + 1 + ty; i < NB; i += 16) {
-            const double lik = At[i][k] * inv;
-            for (int jj = k + 1 + tx; jj <= i; jj += 16) At[i][jj] -= lik * (At[jj][k] * inv);
+        __syncthreads();   // column buffer no longer read: Lt becomes the output tile
+        for (int e = tid; e < NB * (NB + 1); e += 256) (&Lt[0][0])[e] = 0.0;
+        __syncthreads();
+        if (bj <= bi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * bi + r >= 4 * bj + c) Lt[4 * bi + r][4 * bj + c] = a[r][c];
         }
     }
     __syncthreads();
