@@ -85,6 +85,7 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
     if (perm) perm->clear();
     // iterative post-order with child reordering
     struct Frame { int node, stage; };
+    std::vector<int> dev_index(nodes.size(), -1);
     std::vector<Frame> fs{{stack.back(), 0}};
     while (!fs.empty()) {
         Frame &f = fs.back();
@@ -95,6 +96,10 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
             if (op == NGP_OP_CHANGEPOINT && swap) op = OP_CP_SWAPPED;
             if (nd.op >= NGP_OP_SQEXP && nd.op <= NGP_OP_PERIODIC) out->slot[no] = (uint8_t)nstat++;
             if (nd.op == NGP_OP_CHANGEPOINT) out->slot[no] = (uint8_t)ncp++;
+            if (nd.op >= NGP_OP_PLUS)
+                out->first[no] = (uint8_t)dev_index[(size_t)(swap ? nd.right : nd.left)];
+            out->poff[no] = (uint8_t)np;
+            dev_index[(size_t)f.node] = no;
             out->ops[no++] = (uint8_t)op;
             for (int q = 0; q < k_nparams[nd.op]; ++q) {
                 out->params[np++] = k->params[nd.pfirst + q];
@@ -367,6 +372,59 @@ struct EventTimer {  // HIP events on the launch stream, resolved after the job'
     }
 };
 
+
+// The left-looking factorisation of one chunk (every item's block columns in lock step).
+// Block columns in pairs: a FAT step finishes column jj and pre-accumulates column jj+1 (and,
+// on a side stream, the diagonal tile of jj+2) from the same streamed rows; the THIN step that
+// follows only adds k in [64 (jj-1), 64 jj).  See chol_col_lds_kernel.
+void factor_chunk(ngp_ctx *c, const JobGeom &g, const ChunkPtrs &p, int bc, EventTimer &tm) {
+    hipStream_t s = c->stream;
+    const double nrows_aux = (double)g.naux;
+    bool ahead_pending = false;
+    for (int jj = 0; jj < g.nb0; ++jj) {
+        const bool fat = (jj % 2 == 0) && (jj + 1 < g.nb0);
+        const bool thin = (jj % 2 == 1);
+        const int mode = fat ? COL_FAT : (thin ? COL_THIN : COL_FULL);
+        const int ahead = (fat && jj + 2 < g.nb0) ? 1 : 0;
+        const int k0_col = thin ? (jj - 1) * NB : 0;
+        // diag tile (jj,jj): odd jj pre-accumulated over k < 64 (jj-1) by the fat step
+        // jj-1; even jj >= 2 pre-accumulated over k < 64 (jj-2) by its diag-ahead tile
+        const int k0_diag = thin ? (jj - 1) * NB : (jj >= 2 ? (jj - 2) * NB : 0);
+        const double k = (double)jj * NB;
+        const double kd = k - k0_diag;
+        // the diag-ahead tile (jj, jj) was launched on the side stream at step jj-2, beside
+        // diag(jj-1) / col(jj-1); chol_diag(jj) is its only consumer
+        if (ahead_pending && (jj % 2 == 0)) {
+            (void)hipStreamWaitEvent(s, c->ev_join, 0);
+            ahead_pending = false;
+        }
+        tm.run(1, bc * ((double)NB * NB * kd + (double)NB * NB * NB / 3.0),
+               bc * 8.0 * (NB * kd + 2.0 * NB * NB),
+               [&] { launch_chol_diag(g, p, bc, jj, k0_diag, s); });
+        const double rows = (double)(g.n0 - (jj + 1) * NB) + nrows_aux;
+        const double kc = k - k0_col;
+        double fl = rows * (2.0 * NB * kc + (double)NB * NB);
+        double by = 8.0 * (rows * kc + NB * kc + 2.0 * rows * NB);
+        if (fat) {  // + column jj+1 partial sums from the same rows
+            fl += rows * 2.0 * NB * k;
+            by += 8.0 * (NB * k + 2.0 * rows * NB);
+        }
+        tm.run(0, bc * fl, bc * by,
+               [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, ahead, s); });
+        if (ahead && jj > 0) {
+            (void)hipEventRecord(c->ev_fork, s);
+            (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
+            launch_diag_ahead(g, p, bc, jj, c->side);
+            (void)hipEventRecord(c->ev_join, c->side);
+            ahead_pending = true;
+        }
+    }
+    if (ahead_pending) {
+        (void)hipStreamWaitEvent(s, c->ev_join, 0);
+        ahead_pending = false;
+    }
+}
+
 template <class T> ngp_status job_alloc(ngp_job *j, T **p, size_t count) {
     void *v = nullptr;
     ngp_status st = j->ctx->alloc(&v, count * sizeof(T));
@@ -413,6 +471,8 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     g.ld = g.n0;
     g.item_stride = (int64_t)(g.n0 + g.naux_pad) * g.n0;
     g.npts = g.n0 + g.da + m;
+    g.n_real = g.n0;
+    g.aux_identity = 0;
     g.maxstat = std::max(maxstat, 1);
     g.maxcp = std::max(maxcp, 1);
     std::vector<int32_t> h_q;
@@ -548,52 +608,7 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
             const double fill_elems =
                 (double)bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0);
             tm.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, s); });
-            // Block columns in pairs: a FAT step finishes column jj and pre-accumulates column
-            // jj+1 (and the diagonal tile of jj+2) from the same streamed rows; the THIN step that
-            // follows only adds k in [64 (jj-1), 64 jj).  See chol_col_kernel.
-            bool ahead_pending = false;
-            for (int jj = 0; jj < g.nb0; ++jj) {
-                const bool fat = (jj % 2 == 0) && (jj + 1 < g.nb0);
-                const bool thin = (jj % 2 == 1);
-                const int mode = fat ? COL_FAT : (thin ? COL_THIN : COL_FULL);
-                const int ahead = (fat && jj + 2 < g.nb0) ? 1 : 0;
-                const int k0_col = thin ? (jj - 1) * NB : 0;
-                // diag tile (jj,jj): odd jj pre-accumulated over k < 64 (jj-1) by the fat step
-                // jj-1; even jj >= 2 pre-accumulated over k < 64 (jj-2) by its diag-ahead tile
-                const int k0_diag = thin ? (jj - 1) * NB : (jj >= 2 ? (jj - 2) * NB : 0);
-                const double k = (double)jj * NB;
-                const double kd = k - k0_diag;
-                // the diag-ahead tile (jj, jj) was launched on the side stream at step jj-2, beside
-                // diag(jj-1) / col(jj-1); chol_diag(jj) is its only consumer
-                if (ahead_pending && (jj % 2 == 0)) {
-                    (void)hipStreamWaitEvent(s, c->ev_join, 0);
-                    ahead_pending = false;
-                }
-                tm.run(1, bc * ((double)NB * NB * kd + (double)NB * NB * NB / 3.0),
-                       bc * 8.0 * (NB * kd + 2.0 * NB * NB),
-                       [&] { launch_chol_diag(g, p, bc, jj, k0_diag, s); });
-                const double rows = (double)(g.n0 - (jj + 1) * NB) + nrows_aux;
-                const double kc = k - k0_col;
-                double fl = rows * (2.0 * NB * kc + (double)NB * NB);
-                double by = 8.0 * (rows * kc + NB * kc + 2.0 * rows * NB);
-                if (fat) {  // + column jj+1 partial sums from the same rows
-                    fl += rows * 2.0 * NB * k;
-                    by += 8.0 * (NB * k + 2.0 * rows * NB);
-                }
-                tm.run(0, bc * fl, bc * by,
-                       [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, ahead, s); });
-                if (ahead && jj > 0) {
-                    (void)hipEventRecord(c->ev_fork, s);
-                    (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
-                    launch_diag_ahead(g, p, bc, jj, c->side);
-                    (void)hipEventRecord(c->ev_join, c->side);
-                    ahead_pending = true;
-                }
-            }
-            if (ahead_pending) {
-                (void)hipStreamWaitEvent(s, c->ev_join, 0);
-                ahead_pending = false;
-            }
+            factor_chunk(c, g, p, bc, tm);
             tm.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0, [&] {
                 launch_gram(g, (const double *)Lbuf, j->G + (int64_t)b0 * g.naux * g.naux, bc, s);
             });
@@ -774,10 +789,156 @@ extern "C" ngp_status ngp_cov_batch(ngp_ctx *c, int32_t B, const ngp_kernel *ker
     return e == hipSuccess ? NGP_OK : (ngp_status)e;
 }
 
-extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *, int32_t, const ngp_kernel *, int32_t,
-                                           const double *, const double *, int64_t, double *,
-                                           double *, int32_t *) {
-    return NGP_ERR_STATE;  // gradient path: see ngp_grad.hip once built
+extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kernel *kernels,
+                                           int32_t n, const double *t, const double *y,
+                                           int64_t ldy, double *logml, double *grad,
+                                           int32_t *info) {
+    if (!c || !kernels || !t || !y || !grad || B <= 0 || n <= 0) return NGP_ERR_ARG;
+    std::vector<DevProgram> hp((size_t)B);
+    std::vector<std::vector<int>> perm((size_t)B);
+    int maxstat = 0, maxcp = 0;
+    for (int i = 0; i < B; ++i) {
+        int ns = 0, nc = 0;
+        ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], &perm[(size_t)i], &ns, &nc);
+        if (st) return st;
+        maxstat = std::max(maxstat, ns);
+        maxcp = std::max(maxcp, nc);
+    }
+    // Geometry: the matrix is padded to a multiple of 64 with identity rows/cols (log 1 = 0, a
+    // zero in y), and the aux block is [I ; y'] so that the factorisation leaves W = [L^-T ; z'].
+    JobGeom g{};
+    g.B = B;
+    g.n0 = (n + NB - 1) / NB * NB;
+    g.nb0 = g.n0 / NB;
+    g.n_real = n;
+    g.aux_identity = 1;
+    g.naux = g.n0 + 1;
+    g.naux_pad = g.n0 + NB;
+    g.D = 1;
+    g.y_shared = (ldy == 0) ? 1 : 0;
+    g.ld = g.n0;
+    g.item_stride = (int64_t)(g.n0 + g.naux_pad) * g.n0;
+    g.npts = g.n0;
+    g.maxstat = std::max(maxstat, 1);
+    g.maxcp = std::max(maxcp, 1);
+    std::vector<double> h_t((size_t)g.n0, t[n - 1]);
+    for (int i = 0; i < n; ++i) h_t[(size_t)i] = t[i];
+    std::vector<int32_t> h_q;
+    {
+        std::vector<double> real(t, t + n);
+        double hh = 0.0;
+        int R = 0;
+        if (detect_lattice(real, &hh, &h_q, &R)) {
+            g.lattice = 1;
+            g.h = hh;
+            g.R = R;
+            h_q.resize((size_t)g.n0, 0);
+        }
+    }
+    const int ny = g.y_shared ? 1 : B;
+    std::vector<double> h_y((size_t)ny * g.n0, 0.0);
+    for (int b = 0; b < ny; ++b)
+        for (int i = 0; i < n; ++i) h_y[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
+
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const DevSpec sp = dev_spec(c->spec);
+    const int ntri = g.nb0 * (g.nb0 + 1) / 2;
+    const int GP = NGP_MAX_PARAMS + 1;
+    std::vector<void *> owned;
+    auto freeall = [&] { for (void *q : owned) c->release(q); };
+    auto dalloc = [&](void **q, size_t bytes) -> ngp_status {
+        ngp_status st = c->alloc(q, bytes);
+        if (!st) owned.push_back(*q);
+        return st;
+    };
+    const size_t l_bytes = (size_t)g.item_stride * 8;
+    const size_t tab_bytes = g.lattice ? 8 * (size_t)g.maxstat * g.R : 0;
+    const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
+    const size_t item_bytes = l_bytes + tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 +
+                              8 * (size_t)g.n0 + 8 * (size_t)ntri * GP;
+    int Bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, c->mem_cap / item_bytes));
+    void *d_prog, *d_t, *d_y, *d_q = nullptr, *d_logdet, *d_info, *d_L, *d_dinv, *d_tab = nullptr,
+         *d_sig = nullptr, *d_kinv, *d_alpha, *d_quad, *d_part, *d_grad, *d_logml;
+    ngp_status st;
+    if ((st = dalloc(&d_prog, sizeof(DevProgram) * (size_t)B)) ||
+        (st = dalloc(&d_t, 8 * (size_t)g.n0)) || (st = dalloc(&d_y, 8 * h_y.size())) ||
+        (g.lattice && (st = dalloc(&d_q, 4 * (size_t)g.n0))) ||
+        (st = dalloc(&d_logdet, 8 * (size_t)B)) || (st = dalloc(&d_info, 4 * (size_t)B)) ||
+        (st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
+        (st = dalloc(&d_dinv, 8 * (size_t)Bc * (NB / TB) * TB * TB)) ||
+        (g.lattice && ((st = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
+                       (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)))) ||
+        (st = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||
+        (st = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) || (st = dalloc(&d_quad, 8 * (size_t)Bc)) ||
+        (st = dalloc(&d_part, 8 * (size_t)Bc * ntri * GP)) ||
+        (st = dalloc(&d_grad, 8 * (size_t)B * GP)) || (st = dalloc(&d_logml, 8 * (size_t)B))) {
+        freeall();
+        return st;
+    }
+    hipError_t e = hipMemcpyAsync(d_prog, hp.data(), sizeof(DevProgram) * (size_t)B,
+                                  hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_t, h_t.data(), 8 * h_t.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_y, h_y.data(), 8 * h_y.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && g.lattice)
+        e = hipMemcpyAsync(d_q, h_q.data(), 4 * (size_t)g.n0, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_logdet, 0, 8 * (size_t)B, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, 4 * (size_t)B, s);
+    if (e != hipSuccess) { freeall(); return (ngp_status)e; }
+    EventTimer tm(c->profiling, s);
+    for (int b0 = 0; b0 < B; b0 += Bc) {
+        const int bc = std::min(Bc, B - b0);
+        ChunkPtrs p{};
+        p.L = (double *)d_L;
+        p.dinv = (double *)d_dinv;
+        p.progs = (const DevProgram *)d_prog + b0;
+        p.t0 = (const double *)d_t;
+        p.taux = (const double *)d_t;
+        p.y0 = (const double *)d_y + (g.y_shared ? 0 : (int64_t)b0 * g.n0);
+        p.logdet = (double *)d_logdet + b0;
+        p.info = (int32_t *)d_info + b0;
+        p.tab = (double *)d_tab;
+        p.sig = (double *)d_sig;
+        p.qpts = (const int32_t *)d_q;
+        if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
+        tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + (double)g.naux * g.n0),
+               [&] { launch_fill(g, p, bc, sp, s); });
+        factor_chunk(c, g, p, bc, tm);
+        const double n3 = (double)g.n0 * g.n0 * g.n0;
+        tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
+            launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
+                             (double *)d_quad, bc, s);
+        });
+        tm.run(5, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
+            launch_grad_contract(g, p.progs, (const double *)d_t, (const double *)d_kinv,
+                                 (const double *)d_alpha, (const double *)d_quad, p.logdet,
+                                 (double *)d_part, (double *)d_grad + (int64_t)b0 * GP,
+                                 (double *)d_logml + b0, bc, sp, s);
+        });
+    }
+    std::vector<double> h_grad((size_t)B * GP), h_lm((size_t)B);
+    std::vector<int32_t> h_info((size_t)B);
+    e = hipMemcpyAsync(h_grad.data(), d_grad, 8 * h_grad.size(), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_lm.data(), d_logml, 8 * (size_t)B, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_info.data(), d_info, 4 * (size_t)B, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    tm.resolve(c->prof);
+    freeall();
+    if (e != hipSuccess) return (ngp_status)e;
+    // device parameter order -> caller's order; d/d noise last
+    size_t off = 0;
+    for (int i = 0; i < B; ++i) {
+        const int np = kernels[i].n_params;
+        for (int k = 0; k < np; ++k)
+            grad[off + (size_t)perm[(size_t)i][(size_t)k]] = h_grad[(size_t)i * GP + (size_t)k];
+        grad[off + (size_t)np] = h_grad[(size_t)i * GP + (size_t)np];
+        off += (size_t)np + 1;
+        if (logml) logml[i] = h_lm[(size_t)i];
+        if (info) info[i] = h_info[(size_t)i];
+    }
+    return NGP_OK;
 }
 
 extern "C" ngp_status ngp_weights_normalize(int32_t P, const double *logw, double *w_norm,

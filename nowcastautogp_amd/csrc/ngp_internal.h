@@ -24,6 +24,8 @@ struct DevProgram {
     double  noise;               // observation-noise variance (jitter is in the spec)
     uint8_t ops[NGP_MAX_OPS];
     uint8_t slot[NGP_MAX_OPS];   // per op: table slot (stationary leaf) or sigmoid slot (ChangePoint)
+    uint8_t first[NGP_MAX_OPS];  // binary ops: index of the operand evaluated first (the second is i-1)
+    uint8_t poff[NGP_MAX_OPS];   // per op: offset of its parameters in params[]
     double  params[NGP_MAX_PARAMS];
 };
 static_assert(sizeof(DevProgram) % 8 == 0, "DevProgram is copied as 8-byte words");
@@ -52,6 +54,8 @@ struct JobGeom {
     int32_t npts;      // n0 + da + m points that carry a time
     int32_t maxstat;   // stationary-leaf table slots per item
     int32_t maxcp;     // ChangePoint sigmoid slots per item
+    int32_t n_real;    // main-block points that are data; rows/cols beyond are identity padding
+    int32_t aux_identity;  // 1: aux rows are [I_n0 ; y'] (gradient path: W = L^-T)
     int32_t pad0;
     double  h;         // lattice step
     int64_t ld;        // row stride of the factor storage (= n0)
@@ -96,6 +100,12 @@ enum { COL_FULL = 0, COL_FAT = 1, COL_THIN = 2 };
 void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mode, int k0,
                      int ahead, hipStream_t s);
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
+void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
+                      int Bc, hipStream_t s);
+void launch_grad_contract(const JobGeom &g, const DevProgram *progs, const double *t0,
+                          const double *Kinv, const double *alpha, const double *quad,
+                          const double *logdet, double *partials, double *grad, double *logml,
+                          int Bc, const DevSpec &sp, hipStream_t s);
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s);
 void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipStream_t s);
 void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2,

@@ -247,6 +247,13 @@ __global__ __launch_bounds__(256) void fill_kernel(JobGeom g, ChunkPtrs p, int n
             v.y = keval(P, sp, t1, t2b);
             if (row == col) v.x += diag;
             if (row == col + 1) v.y += diag;
+            if (row >= g.n_real || col >= g.n_real) v.x = (row == col) ? 1.0 : 0.0;
+            if (row >= g.n_real || col + 1 >= g.n_real) v.y = (row == col + 1) ? 1.0 : 0.0;
+        } else if (g.aux_identity) {
+            const int ar = r * NB + lr;
+            row = (long)g.n0 + ar;
+            v.x = ar < g.n0 ? (ar == col ? 1.0 : 0.0) : (ar == g.n0 ? y0[col] : 0.0);
+            v.y = ar < g.n0 ? (ar == col + 1 ? 1.0 : 0.0) : (ar == g.n0 ? y0[col + 1] : 0.0);
         } else {
             const int ar = r * NB + lr;
             row = (long)g.n0 + ar;
@@ -407,6 +414,13 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
             v.y = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2b, abs(q1 - q2b), (int)row, col + 1);
             if (row == col) v.x += diag;
             if (row == col + 1) v.y += diag;
+            if (row >= g.n_real || col >= g.n_real) v.x = (row == col) ? 1.0 : 0.0;
+            if (row >= g.n_real || col + 1 >= g.n_real) v.y = (row == col + 1) ? 1.0 : 0.0;
+        } else if (g.aux_identity) {
+            const int ar = r * NB + lr;
+            row = (long)g.n0 + ar;
+            v.x = ar < g.n0 ? (ar == col ? 1.0 : 0.0) : (ar == g.n0 ? y0[col] : 0.0);
+            v.y = ar < g.n0 ? (ar == col + 1 ? 1.0 : 0.0) : (ar == g.n0 ? y0[col + 1] : 0.0);
         } else {
             const int ar = r * NB + lr;
             row = (long)g.n0 + ar;
@@ -1108,6 +1122,226 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
 }
 
 // ---------------------------------------------------------------------------------------
+// gradient of the log marginal likelihood (HMC inside fit_smc! / mcmc_parameters!)
+//   d logml / d theta_p = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij / d theta_p
+// The factorisation above ran with aux rows [I ; y'], so the aux block is W = [L^-T ; z'] and
+//   Kinv = W_I W_I'  (MFMA Gram, upper-triangular W: k starts at the row tile),  alpha = W_I z.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void grad_kinv_kernel(JobGeom g, const double *L,
+                                                           double *Kinv, int npairs) {
+    const int item = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pr = blockIdx.x * 4 + wave;
+    if (pr >= npairs) return;
+    int I = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= pr) ++I;
+    while (I * (I + 1) / 2 > pr) --I;
+    const int J = pr - I * (I + 1) / 2;   // I >= J
+    const long ld = g.ld;
+    const double *W = L + (long)item * g.item_stride + (long)g.n0 * ld;
+    const int r16 = lane & 15, q = lane >> 4;
+    double acc4[4][4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
+    // S'[jj][i] = sum_k W[64J + jj][k] W[64I + i][k]; W[a][k] = 0 for k < a, so k >= 64 I
+    const double *pa = W + (long)(J * NB + r16) * ld + 2 * q;
+    const double *pb = W + (long)(I * NB + r16) * ld + 2 * q;
+    gemm_rows<4>(acc4, pa, pb, ld, I * NB, g.n0);
+    double *Ko = Kinv + (long)item * g.n0 * g.n0;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const f64x4 d = to_d16(acc4[jt][it]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                Ko[(long)(I * NB + 16 * it + r16) * g.n0 + J * NB + 16 * jt + q + 4 * s] = d[s];
+        }
+}
+
+// alpha[a] = sum_k W[a][k] z[k] (z = the data row of W), quad = z'z; one wave per row
+__global__ __launch_bounds__(256) void grad_alpha_kernel(JobGeom g, const double *L, double *alpha,
+                                                         double *quad) {
+    const int item = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int a = blockIdx.x * 4 + wave;   // a == n0: the quadratic form
+    if (a > g.n0) return;
+    const double *W = L + (long)item * g.item_stride + (long)g.n0 * g.ld;
+    const double *wa = W + (long)a * g.ld, *z = W + (long)g.n0 * g.ld;
+    double s = 0.0;
+    for (int k = lane; k < g.n0; k += 64) s += wa[k] * z[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        if (a < g.n0) alpha[(long)item * g.n0 + a] = s;
+        else quad[item] = s;
+    }
+}
+
+// Reverse-mode sweep of the kernel tree per matrix element, contracted with
+// w_ij = alpha_i alpha_j - Kinv_ij (lower triangle; the diagonal carries 1/2).
+__global__ __launch_bounds__(256) void grad_contract_kernel(JobGeom g, const DevProgram *progs,
+                                                            const double *t0, const double *Kinv,
+                                                            const double *alpha, double *partials,
+                                                            int ntri, DevSpec sp) {
+    __shared__ DevProgram P;
+    __shared__ double red[4][NGP_MAX_PARAMS + 1];
+    const int item = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    load_program(&P, progs + item);
+    __syncthreads();
+    int r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+    while (r * (r + 1) / 2 > tile) --r;
+    const int c = tile - r * (r + 1) / 2;
+    const int tx = tid & 63, ty = tid >> 6;
+    const int col = c * NB + tx;
+    const int np = P.n_params, nops = P.n_ops;
+    double gacc[NGP_MAX_PARAMS + 1];
+    for (int i = 0; i <= np; ++i) gacc[i] = 0.0;
+    const double *Ki = Kinv + (long)item * g.n0 * g.n0;
+    const double *al = alpha + (long)item * g.n0;
+    if (col < g.n_real) {
+        const double t2 = t0[col], ac = al[col];
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = r * NB + ty * 16 + rr;
+            if (row >= g.n_real || col > row) continue;
+            double w = al[row] * ac - Ki[(long)row * g.n0 + col];
+            if (row == col) w *= 0.5;
+            const double t1 = t0[row];
+            const double d = fabs(t1 - t2);
+            // ---- forward sweep: value of every node
+            double val[NGP_MAX_OPS];
+            for (int i = 0; i < nops; ++i) {
+                const int op = P.ops[i], po = P.poff[i];
+                double v;
+                if (op == NGP_OP_CONSTANT) v = P.params[po];
+                else if (op == NGP_OP_LINEAR)
+                    v = P.params[po + 1] + P.params[po + 2] * (t1 - P.params[po]) * (t2 - P.params[po]);
+                else if (op == NGP_OP_SQEXP) {
+                    const double l = P.params[po];
+                    v = P.params[po + 1] * exp(-0.5 * d * d / (sp.se_form ? l : l * l));
+                } else if (op == NGP_OP_GAMMAEXP)
+                    v = P.params[po + 2] * exp(-pow(d / P.params[po], P.params[po + 1]));
+                else if (op == NGP_OP_PERIODIC) {
+                    const double l = P.params[po], sn = sin(M_PI * d / P.params[po + 1]);
+                    v = P.params[po + 2] * exp(-(sp.periodic_form ? 2.0 / l : 2.0 / (l * l)) * sn * sn);
+                } else {
+                    const double x = val[P.first[i]], y = val[i - 1];   // first-evaluated, second
+                    if (op == NGP_OP_PLUS) v = x + y;
+                    else if (op == NGP_OP_TIMES) v = x * y;
+                    else {
+                        const double kl = (op == NGP_OP_CHANGEPOINT) ? x : y;
+                        const double kr = (op == NGP_OP_CHANGEPOINT) ? y : x;
+                        const double g1 = cp_sigma(sp.cp_form, t1, P.params[po], P.params[po + 1]);
+                        const double g2 = cp_sigma(sp.cp_form, t2, P.params[po], P.params[po + 1]);
+                        v = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+                    }
+                }
+                val[i] = v;
+            }
+            // ---- reverse sweep: adjoint stack mirrors the evaluation stack
+            double s0 = w, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+            for (int i = nops - 1; i >= 0; --i) {
+                const int op = P.ops[i], po = P.poff[i];
+                const double a = s0;
+                s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;   // pop
+                if (op == NGP_OP_CONSTANT) {
+                    gacc[po] += a;
+                } else if (op == NGP_OP_LINEAR) {
+                    const double cc = P.params[po], a1 = t1 - cc, a2 = t2 - cc;
+                    gacc[po] += a * P.params[po + 2] * (-a1 - a2);
+                    gacc[po + 1] += a;
+                    gacc[po + 2] += a * a1 * a2;
+                } else if (op == NGP_OP_SQEXP) {
+                    const double l = P.params[po], am = P.params[po + 1];
+                    const double e = exp(-0.5 * d * d / (sp.se_form ? l : l * l));
+                    gacc[po] += a * (sp.se_form ? am * e * 0.5 * d * d / (l * l)
+                                                : am * e * d * d / (l * l * l));
+                    gacc[po + 1] += a * e;
+                } else if (op == NGP_OP_GAMMAEXP) {
+                    const double l = P.params[po], gm = P.params[po + 1], am = P.params[po + 2];
+                    const double rr_ = d / l, u = pow(rr_, gm), e = exp(-u);
+                    gacc[po] += a * am * e * gm * u / l;
+                    gacc[po + 1] += (d > 0.0) ? -a * am * e * u * log(rr_) : 0.0;
+                    gacc[po + 2] += a * e;
+                } else if (op == NGP_OP_PERIODIC) {
+                    const double l = P.params[po], per = P.params[po + 1], am = P.params[po + 2];
+                    const double ang = M_PI * d / per, sn = sin(ang), cs = cos(ang);
+                    const double cq = sp.periodic_form ? 2.0 / l : 2.0 / (l * l);
+                    const double e = exp(-cq * sn * sn);
+                    gacc[po] += a * (sp.periodic_form ? am * e * 2.0 * sn * sn / (l * l)
+                                                      : am * e * 4.0 * sn * sn / (l * l * l));
+                    gacc[po + 1] += a * am * e * cq * 2.0 * sn * cs * M_PI * d / (per * per);
+                    gacc[po + 2] += a * e;
+                } else {
+                    const double x = val[P.first[i]], y = val[i - 1];
+                    double ax, ay;   // adjoints of the first-evaluated and the second operand
+                    if (op == NGP_OP_PLUS) {
+                        ax = a; ay = a;
+                    } else if (op == NGP_OP_TIMES) {
+                        ax = a * y; ay = a * x;
+                    } else {
+                        const bool nat = (op == NGP_OP_CHANGEPOINT);
+                        const double kl = nat ? x : y, kr = nat ? y : x;
+                        const double loc = P.params[po], sc = P.params[po + 1];
+                        const double sgn = sp.cp_form ? 1.0 : -1.0;   // u = sgn (t - loc) / sc
+                        const double u1 = sgn * (t1 - loc) / sc, u2 = sgn * (t2 - loc) / sc;
+                        const double th1 = tanh(u1), th2 = tanh(u2);
+                        const double g1 = 0.5 * (1.0 + th1), g2 = 0.5 * (1.0 + th2);
+                        const double q1 = 0.5 * (1.0 - th1 * th1), q2 = 0.5 * (1.0 - th2 * th2);
+                        const double d1l = q1 * (-sgn / sc), d2l = q2 * (-sgn / sc);
+                        const double d1s = q1 * (-u1 / sc), d2s = q2 * (-u2 / sc);
+                        gacc[po] += a * (d1l * kl * g2 + g1 * kl * d2l - d1l * kr * (1.0 - g2) -
+                                         (1.0 - g1) * kr * d2l);
+                        gacc[po + 1] += a * (d1s * kl * g2 + g1 * kl * d2s - d1s * kr * (1.0 - g2) -
+                                             (1.0 - g1) * kr * d2s);
+                        const double al_ = a * g1 * g2, ar_ = a * (1.0 - g1) * (1.0 - g2);
+                        ax = nat ? al_ : ar_;
+                        ay = nat ? ar_ : al_;
+                    }
+                    // push: the second operand (root at i-1) is visited next, so it goes on top
+                    s7 = s5; s6 = s4; s5 = s3; s4 = s2; s3 = s1; s2 = s0; s1 = ax; s0 = ay;
+                }
+            }
+            if (row == col) gacc[np] += w;   // d K / d noise = I (w already carries the 1/2)
+        }
+    }
+    // ---- deterministic reduction: wave shuffles, then the four waves in order
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int pidx = 0; pidx <= np; ++pidx) {
+        double v = gacc[pidx];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][pidx] = v;
+    }
+    __syncthreads();
+    if (tid <= np)
+        partials[((long)item * ntri + tile) * (NGP_MAX_PARAMS + 1) + tid] =
+            red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+__global__ __launch_bounds__(128) void grad_reduce_kernel(JobGeom g, const DevProgram *progs,
+                                                          const double *partials, const double *quad,
+                                                          const double *logdet, double *grad,
+                                                          double *logml, int ntri) {
+    const int item = blockIdx.x, pidx = threadIdx.x;
+    const int np = progs[item].n_params;
+    if (pidx <= np) {
+        double s = 0.0;
+        for (int t = 0; t < ntri; ++t)
+            s += partials[((long)item * ntri + t) * (NGP_MAX_PARAMS + 1) + pidx];
+        grad[(long)item * (NGP_MAX_PARAMS + 1) + pidx] = s;
+    }
+    if (pidx == 0)
+        logml[item] = -0.5 * quad[item] - logdet[item] - 0.5 * g.n_real * 1.8378770664093454836;
+}
+
+// ---------------------------------------------------------------------------------------
 // microbenchmarks / self tests
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mfma_bench_kernel(double *out, int iters) {
@@ -1225,6 +1459,26 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
 
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {
     hipLaunchKernelGGL(diag_ahead_kernel, dim3(Bc), dim3(64), 0, s, g, p, j);
+}
+
+void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
+                      int Bc, hipStream_t s) {
+    const int npairs = g.nb0 * (g.nb0 + 1) / 2;
+    hipLaunchKernelGGL(grad_kinv_kernel, dim3((npairs + 3) / 4, Bc), dim3(256), 0, s, g, L, Kinv,
+                       npairs);
+    hipLaunchKernelGGL(grad_alpha_kernel, dim3((g.n0 + 1 + 3) / 4, Bc), dim3(256), 0, s, g, L,
+                       alpha, quad);
+}
+
+void launch_grad_contract(const JobGeom &g, const DevProgram *progs, const double *t0,
+                          const double *Kinv, const double *alpha, const double *quad,
+                          const double *logdet, double *partials, double *grad, double *logml,
+                          int Bc, const DevSpec &sp, hipStream_t s) {
+    const int ntri = g.nb0 * (g.nb0 + 1) / 2;
+    hipLaunchKernelGGL(grad_contract_kernel, dim3(ntri, Bc), dim3(256), 0, s, g, progs, t0, Kinv,
+                       alpha, partials, ntri, sp);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(Bc), dim3(128), 0, s, g, progs, partials, quad,
+                       logdet, grad, logml, ntri);
 }
 
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s) {
