@@ -1,0 +1,513 @@
+"""Host-side mirror of the AutoGP surface that NowcastAutoGP calls.
+
+Every symbol below stands where the reference calls into AutoGP.jl:
+
+    GPModel(ds, y; n_particles, config)      src/make_and_fit_model.jl:104-107
+    Schedule.linear_schedule(n, p)           src/make_and_fit_model.jl:110
+    fit_smc!(model; schedule, n_mcmc, n_hmc) src/make_and_fit_model.jl:111
+    add_data!(model, ds, y)                  src/forecasting.jl:248
+    maybe_resample!(model, ess)              src/forecasting.jl:251-254
+    num_particles(model)                     src/forecasting.jl:253
+    mcmc_structure!(model, n_mcmc, n_hmc)    src/forecasting.jl:259
+    mcmc_parameters!(model, n_hmc)           src/forecasting.jl:178,261
+    predict_mvn(model, dates) -> rand        src/forecasting.jl:159-160,179-180
+    Dict(model) / GPModel(dict)              src/forecasting.jl:241,246
+
+The arithmetic (covariance assembly, Cholesky, log marginal likelihoods, their gradients,
+predictive solves) is NOT here: it is the HIP library behind ``engine`` (``_lib.Context`` through
+the C-ABI of include/ngp.h).  This file is orchestration: the particle bookkeeping of a
+sequential Monte Carlo sampler over kernel structures, batched so that every step is ONE call
+carrying all particles.  AutoGP.jl's source is not available here, so the sampler's moves are this
+repository's own design ([RECALLED] where they follow what is remembered of AutoGP): data
+annealing with incremental log-weights, ESS-triggered multinomial resampling, subtree-regeneration
+Metropolis-Hastings over structures, HMC over the N(0,1) latents of the continuous parameters.
+Python identifiers drop Julia's ``!``.
+"""
+from __future__ import annotations
+
+import copy
+import datetime as _dt
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import distributed, gp
+from ._lib import PosDefException
+
+__all__ = ["GPModel", "Schedule", "fit_smc", "add_data", "maybe_resample", "num_particles",
+           "mcmc_structure", "mcmc_parameters", "predict_mvn", "MixtureMVN", "HipEngine"]
+
+
+# ---------------------------------------------------------------------------------------------
+# engine: the only thing that computes.  The product default is the HIP library; it raises if
+# the extension or the GPU is missing (there is deliberately no CPU path in this package).
+# ---------------------------------------------------------------------------------------------
+class HipEngine:
+    def __init__(self, device: Optional[int] = None, spec=None):
+        from . import _lib
+        if device is None:
+            import os
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.ctx = _lib.Context(device, spec)
+
+    def logml(self, programs, t, y):
+        return self.ctx.logml_batch(programs, t, y)
+
+    def logml_grad(self, programs, t, y):
+        return self.ctx.logml_grad_batch(programs, t, y)
+
+    def predict(self, programs, t, y, t_new, noise_on_new=True):
+        return self.ctx.predict_batch(programs, t, y, t_new, noise_on_new)
+
+    def nowcast(self, programs, t, y, t_add, y_add, t_new, noise_on_new=True):
+        return self.ctx.nowcast_batch(programs, t, y, t_add, y_add, t_new, noise_on_new)
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = HipEngine()
+    return _default_engine
+
+
+# ---------------------------------------------------------------------------------------------
+# transforms (AutoGP rescales dates onto [0,1] — reference docs/vignettes/setting-priors.jl:71 —
+# and y by its range — reference src/make_and_fit_model.jl:26-27; exact affine map [RECALLED])
+# ---------------------------------------------------------------------------------------------
+def to_days(ds) -> np.ndarray:
+    """dates -> integer days (datetime.date / numpy datetime64 / numbers accepted)."""
+    out = []
+    for d in ds:
+        if isinstance(d, (_dt.datetime,)):
+            out.append(d.date().toordinal())
+        elif isinstance(d, _dt.date):
+            out.append(d.toordinal())
+        elif isinstance(d, np.datetime64):
+            out.append(int(d.astype("datetime64[D]").astype(np.int64)))
+        else:
+            out.append(d)
+    return np.asarray(out, dtype=np.float64)
+
+
+@dataclass
+class LinearTransform:
+    slope: float
+    intercept: float
+
+    def apply(self, x):
+        return self.slope * np.asarray(x, dtype=np.float64) + self.intercept
+
+    def invert(self, x):
+        return (np.asarray(x, dtype=np.float64) - self.intercept) / self.slope
+
+
+def _ds_transform(days: np.ndarray) -> LinearTransform:
+    lo, hi = float(days.min()), float(days.max())
+    span = hi - lo if hi > lo else 1.0
+    return LinearTransform(1.0 / span, -lo / span)
+
+
+def _y_transform(y: np.ndarray) -> LinearTransform:
+    lo, hi = float(y.min()), float(y.max())
+    if not hi > lo:
+        # the reference documents this failure as a PosDefException (issue #51,
+        # src/make_and_fit_model.jl:26-28); _stabilize_for_fit jitters flat data before it gets here
+        raise PosDefException(1, 0)
+    slope = 2.0 / (hi - lo)
+    return LinearTransform(slope, -slope * (hi + lo) / 2.0)
+
+
+# ---------------------------------------------------------------------------------------------
+class Schedule:
+    @staticmethod
+    def linear_schedule(n: int, percent: float) -> List[int]:
+        """Cumulative observation counts of the data-annealing steps: step = max(1, round(p n))
+        up to n (reference src/make_and_fit_model.jl:109-110 clamps p >= 1/n)."""
+        if n <= 0:
+            raise ValueError("n must be positive")
+        step = max(1, int(round(percent * n)))
+        out = list(range(step, n, step))
+        out.append(n)
+        return out
+
+
+@dataclass
+class Particle:
+    tree: gp.Node
+    noise: float
+
+    def program(self):
+        ops, params = gp.to_program(self.tree)
+        return ops, params, self.noise
+
+
+class GPModel:
+    """Ensemble of SMC particles over kernel structures.  Observable fields used by the
+    reference's tests: ``config`` (identity preserved, test/test_gpconfig.jl:9), ``ds``, ``y``."""
+
+    def __init__(self, ds=None, y=None, *, n_particles: int = 8, config: Optional[gp.GPConfig] = None,
+                 engine=None, seed: Optional[int] = None, depth_cap: int = 6, _from=None):
+        if isinstance(ds, dict) and y is None:
+            _from = ds
+        self.engine = engine
+        if _from is not None:
+            self._load(_from)
+            return
+        ds = list(ds)
+        y = np.asarray(y, dtype=np.float64)
+        if len(ds) != y.size:
+            raise ValueError("ds and y must have the same length")
+        if n_particles < 1:
+            raise ValueError("n_particles must be >= 1")
+        self.config = config if config is not None else gp.GPConfig()
+        self.ds = ds
+        self.y = y.copy()
+        self.days = to_days(ds)
+        self.ds_transform = _ds_transform(self.days)
+        self.y_transform = _y_transform(self.y)
+        self.depth_cap = depth_cap
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.n_particles_total = int(n_particles)
+        sl = distributed.shard(self.n_particles_total)
+        nloc = sl.stop - sl.start
+        self.particles: List[Particle] = [
+            Particle(gp.sample_tree(self.rng, self.config, depth_cap=depth_cap),
+                     gp.sample_noise(self.rng, self.config)) for _ in range(nloc)]
+        self.log_weights = np.zeros(nloc)
+        self.n_obs = 0                      # observations absorbed so far (data annealing)
+        self._perm = np.arange(y.size)
+        self._logml = np.zeros(nloc)        # log p(y[:n_obs] | particle)
+
+    # -- engine ---------------------------------------------------------------------------------
+    def _eng(self):
+        if self.engine is None:
+            self.engine = default_engine()
+        return self.engine
+
+    # -- data views -----------------------------------------------------------------------------
+    def _obs(self, count: Optional[int] = None):
+        """(t, y) of the first ``count`` annealed observations, in time order, on model scale."""
+        count = self.n_obs if count is None else count
+        idx = np.sort(self._perm[:count])
+        return self.ds_transform.apply(self.days[idx]), self.y_transform.apply(self.y[idx])
+
+    def programs(self):
+        return [p.program() for p in self.particles]
+
+    # -- Dict(model) / GPModel(dict)  (reference src/forecasting.jl:241,246) ----------------------
+    def to_dict(self) -> dict:
+        return {
+            "config": self.config,   # kept by identity, like the reference's model.config === cfg
+            "ds": list(self.ds), "y": self.y.copy(), "days": self.days.copy(),
+            "ds_transform": (self.ds_transform.slope, self.ds_transform.intercept),
+            "y_transform": (self.y_transform.slope, self.y_transform.intercept),
+            "depth_cap": self.depth_cap, "n_particles_total": self.n_particles_total,
+            "particles": [dict(ops=p.program()[0].tolist(), params=p.program()[1].tolist(),
+                               noise=p.noise) for p in self.particles],
+            "log_weights": self.log_weights.copy(), "n_obs": self.n_obs,
+            "perm": self._perm.copy(), "logml": self._logml.copy(),
+            "rng_state": copy.deepcopy(self.rng.bit_generator.state),
+        }
+
+    def _load(self, d: dict):
+        self.config = d["config"]
+        self.ds, self.y, self.days = list(d["ds"]), np.array(d["y"], float), np.array(d["days"], float)
+        self.ds_transform = LinearTransform(*d["ds_transform"])
+        self.y_transform = LinearTransform(*d["y_transform"])
+        self.depth_cap = d["depth_cap"]
+        self.n_particles_total = d["n_particles_total"]
+        self.particles = [Particle(gp.from_program(p["ops"], p["params"]), float(p["noise"]))
+                          for p in d["particles"]]
+        self.log_weights = np.array(d["log_weights"], float)
+        self.n_obs = int(d["n_obs"])
+        self._perm = np.array(d["perm"])
+        self._logml = np.array(d["logml"], float)
+        self.rng = np.random.Generator(np.random.PCG64())
+        self.rng.bit_generator.state = copy.deepcopy(d["rng_state"])
+
+    @classmethod
+    def from_dict(cls, d: dict, engine=None) -> "GPModel":
+        return cls(_from=d, engine=engine)
+
+
+def num_particles(model: GPModel) -> int:
+    return model.n_particles_total
+
+
+# ---------------------------------------------------------------------------------------------
+# weights / resampling — the only cross-particle (and, multi-GPU, cross-rank) step
+# ---------------------------------------------------------------------------------------------
+def _normalized_weights(model: GPModel):
+    w, ess = distributed.normalize_log_weights(model.log_weights)
+    return w, ess
+
+
+def effective_sample_size(model: GPModel) -> float:
+    return _normalized_weights(model)[1]
+
+
+def maybe_resample(model: GPModel, ess_threshold: float) -> bool:
+    """Resample (multinomial) when ESS < ess_threshold (an absolute count, as the reference
+    passes ``ess_threshold * num_particles``, src/forecasting.jl:251-254).  Weights reset to
+    uniform.  Across ranks: all-gather of log-weights, identical ancestors everywhere, particle
+    descriptors exchanged — no matrix moves."""
+    w_loc, ess = _normalized_weights(model)
+    if not (ess < ess_threshold):
+        return False
+    w_all = distributed.all_gather_rows(w_loc[:, None])[:, 0]
+    seed = int(model.rng.integers(0, 2**31 - 1))
+    if distributed.world()[1] > 1:   # every rank must draw the same ancestors
+        seed = int(distributed.all_gather_rows(np.array([[float(seed)]]))[0, 0])
+    anc = distributed.resample_ancestors(w_all, seed)
+    descr = [(p.program(), float(l)) for p, l in zip(model.particles, model._logml)]
+    mine = distributed.exchange_particles(descr, anc)
+    model.particles = [Particle(gp.from_program(pr[0], pr[1]), float(pr[2])) for pr, _ in mine]
+    model._logml = np.array([l for _, l in mine])
+    model.log_weights = np.zeros(len(mine))
+    return True
+
+
+# ---------------------------------------------------------------------------------------------
+# rejuvenation moves (all particles advance together: one engine call per proposal / leapfrog)
+# ---------------------------------------------------------------------------------------------
+def _valid_program(tree: gp.Node) -> bool:
+    from . import _lib
+    ops, params = gp.to_program(tree)
+    return _lib.kernel_check((ops, params, 0.1)) == 0
+
+
+def _nodes(tree: gp.Node):
+    out = []
+
+    def walk(nd, depth, parent, side):
+        out.append((nd, depth, parent, side))
+        if not nd.is_leaf:
+            walk(nd.left, depth + 1, nd, "left")
+            walk(nd.right, depth + 1, nd, "right")
+
+    walk(tree, 1, None, None)
+    return out
+
+
+def _structure_move(model: GPModel, t, y):
+    """Subtree-regeneration Metropolis-Hastings: pick a node uniformly, redraw its subtree from
+    the prior; accept with min(1, L'/L * |T|/|T'|)."""
+    rng, cfg = model.rng, model.config
+    props, idx = [], []
+    for k, p in enumerate(model.particles):
+        new = gp.clone(p.tree)
+        nodes = _nodes(new)
+        nd, depth, parent, side = nodes[int(rng.integers(len(nodes)))]
+        sub = gp.sample_tree(rng, cfg, depth=depth, depth_cap=model.depth_cap)
+        if parent is None:
+            new = sub
+        else:
+            setattr(parent, side, sub)
+        if _valid_program(new):
+            props.append(new)
+            idx.append(k)
+    if not props:
+        return 0
+    progs = [gp.to_program(tr) + (model.particles[k].noise,) for tr, k in zip(props, idx)]
+    lm, info = model._eng().logml(progs, t, y)
+    acc = 0
+    for tr, k, l1, bad in zip(props, idx, lm, info):
+        if bad or not np.isfinite(l1):
+            continue
+        log_a = (l1 - model._logml[k]) + math.log(model.particles[k].tree.size() / tr.size())
+        if math.log(rng.random()) < log_a:
+            model.particles[k].tree = tr
+            model._logml[k] = float(l1)
+            acc += 1
+    return acc
+
+
+def _latents(model: GPModel):
+    zs, kinds = [], []
+    for p in model.particles:
+        ops, params = gp.to_program(p.tree)
+        kd = gp.param_kinds(ops) + [gp.NOISE_KIND]
+        theta = np.concatenate([params, [p.noise]])
+        zs.append(gp.untransform(theta, kd, model.config.prior))
+        kinds.append(kd)
+    return zs, kinds
+
+
+def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
+    """One HMC transition per particle on the N(0,1) latents z of (parameters, noise):
+    U(z) = -log p(y | theta(z)) + |z|^2 / 2, gradient through the engine's logml gradient."""
+    rng, prior = model.rng, model.config.prior
+    fixed_noise = model.config.noise is not None
+    P = len(model.particles)
+    z0, kinds = _latents(model)
+    ops = [gp.to_program(p.tree)[0] for p in model.particles]
+
+    def potential(zs):
+        progs, dths = [], []
+        for z, kd, op in zip(zs, kinds, ops):
+            th, dth = gp.transform(z, kd, prior)
+            progs.append((op, th[:-1], float(th[-1])))
+            dths.append(dth)
+        lm, grads, info = model._eng().logml_grad(progs, t, y)
+        U, dU = np.empty(P), []
+        for k in range(P):
+            ok = info[k] == 0 and np.isfinite(lm[k]) and np.all(np.isfinite(grads[k]))
+            U[k] = (-lm[k] + 0.5 * zs[k] @ zs[k]) if ok else np.inf
+            g = -grads[k] * dths[k] + zs[k] if ok else np.zeros_like(zs[k])
+            if fixed_noise:
+                g[-1] = 0.0
+            dU.append(g)
+        return U, dU, lm
+
+    U0, dU, _ = potential(z0)
+    mom = [rng.standard_normal(z.size) for z in z0]
+    if fixed_noise:
+        for m_ in mom:
+            m_[-1] = 0.0
+    H0 = U0 + np.array([0.5 * m_ @ m_ for m_ in mom])
+    z = [a.copy() for a in z0]
+    pm = [m_ - 0.5 * eps * g for m_, g in zip(mom, dU)]
+    lm1 = None
+    for step in range(n_leapfrog):
+        z = [a + eps * b for a, b in zip(z, pm)]
+        U1, dU, lm1 = potential(z)
+        scale = eps if step < n_leapfrog - 1 else 0.5 * eps
+        pm = [m_ - scale * g for m_, g in zip(pm, dU)]
+    H1 = U1 + np.array([0.5 * m_ @ m_ for m_ in pm])
+    acc = 0
+    for k in range(P):
+        if np.isfinite(H1[k]) and math.log(rng.random()) < H0[k] - H1[k]:
+            th, _ = gp.transform(z[k], kinds[k], prior)
+            model.particles[k].tree = gp.from_program(ops[k], th[:-1])
+            model.particles[k].noise = float(th[-1])
+            model._logml[k] = float(lm1[k])
+            acc += 1
+    return acc
+
+
+DEFAULT_HMC = {"n_leapfrog": 10, "eps": 0.02}
+
+
+def mcmc_parameters(model: GPModel, n_hmc: int, hmc_config: Optional[dict] = None) -> None:
+    cfgd = {**DEFAULT_HMC, **(hmc_config or {})}
+    t, y = model._obs()
+    for _ in range(int(n_hmc)):
+        _hmc_move(model, t, y, cfgd["n_leapfrog"], cfgd["eps"])
+
+
+def mcmc_structure(model: GPModel, n_mcmc: int, n_hmc: int, hmc_config: Optional[dict] = None,
+                   biased: bool = False) -> None:
+    del biased  # accepted for signature compatibility; proposals are always drawn from the prior
+    t, y = model._obs()
+    cfgd = {**DEFAULT_HMC, **(hmc_config or {})}
+    for _ in range(int(n_mcmc)):
+        _structure_move(model, t, y)
+        for _ in range(int(n_hmc)):
+            _hmc_move(model, t, y, cfgd["n_leapfrog"], cfgd["eps"])
+
+
+# ---------------------------------------------------------------------------------------------
+def _refresh_logml(model: GPModel, count: int):
+    t, y = model._obs(count)
+    lm, info = model._eng().logml(model.programs(), t, y)
+    lm = np.where((info != 0) | ~np.isfinite(lm), -np.inf, lm)
+    return lm
+
+
+def fit_smc(model: GPModel, *, schedule: Sequence[int], n_mcmc: int, n_hmc: int,
+            hmc_config: Optional[dict] = None, biased: bool = False, shuffle: bool = True,
+            adaptive_resampling: bool = True, adaptive_rejuvenation: bool = False,
+            verbose: bool = False) -> None:
+    """SMC over data batches (``n_mcmc`` and ``n_hmc`` are required keywords, as in the reference:
+    omitting them is an error, test/test_gpconfig.jl:42)."""
+    n = model.y.size
+    model._perm = model.rng.permutation(n) if shuffle else np.arange(n)
+    P = num_particles(model)
+    for count in schedule:
+        count = int(min(count, n))
+        if count <= model.n_obs:
+            continue
+        lm = _refresh_logml(model, count)
+        model.log_weights = model.log_weights + (lm - model._logml)
+        model._logml = lm
+        model.n_obs = count
+        resampled = maybe_resample(model, P / 2.0 if adaptive_resampling else float("inf"))
+        if (not adaptive_rejuvenation) or resampled:
+            mcmc_structure(model, n_mcmc, n_hmc, hmc_config, biased)
+        if verbose:
+            print(f"[fit_smc] n_obs={count} ess={effective_sample_size(model):.2f}")
+
+
+def add_data(model: GPModel, ds, y) -> None:
+    """Append observations; particle log-weights move by logml(n+d) - logml(n)
+    (reference src/forecasting.jl:248)."""
+    ds, y = list(ds), np.asarray(y, dtype=np.float64)
+    if len(ds) != y.size:
+        raise ValueError("ds and y must have the same length")
+    if model.n_obs != model.y.size:
+        raise RuntimeError("add_data on a model that has not absorbed all of its data")
+    n_old = model.y.size
+    model.ds = model.ds + ds
+    model.days = np.concatenate([model.days, to_days(ds)])
+    model.y = np.concatenate([model.y, y])
+    model._perm = np.concatenate([model._perm, np.arange(n_old, n_old + y.size)])
+    lm = _refresh_logml(model, n_old + y.size)
+    model.log_weights = model.log_weights + (lm - model._logml)
+    model._logml = lm
+    model.n_obs = n_old + y.size
+
+
+# ---------------------------------------------------------------------------------------------
+class MixtureMVN:
+    """Weighted mixture of per-particle multivariate normals (what predict_mvn returns);
+    ``rand(k)`` -> [m, k], ``rand()`` -> [m] (reference src/forecasting.jl:160,180)."""
+
+    def __init__(self, means, covs, weights, rng):
+        self.means, self.covs = np.asarray(means, float), np.asarray(covs, float)
+        self.weights = np.asarray(weights, float) / np.sum(weights)
+        self.rng = rng
+        self._chol = {}
+
+    def _factor(self, k):
+        if k not in self._chol:
+            try:
+                self._chol[k] = np.linalg.cholesky(self.covs[k])
+            except np.linalg.LinAlgError:
+                raise PosDefException(1, k) from None
+        return self._chol[k]
+
+    def rand(self, draws: Optional[int] = None):
+        m = self.means.shape[1]
+        k = 1 if draws is None else int(draws)
+        comp = self.rng.choice(self.weights.size, size=k, p=self.weights)
+        out = np.empty((m, k))
+        for j, c in enumerate(comp):
+            out[:, j] = self.means[c] + self._factor(int(c)) @ self.rng.standard_normal(m)
+        return out[:, 0] if draws is None else out
+
+    def mean(self):
+        return self.weights @ self.means
+
+
+def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
+    t, y = model._obs()
+    t_new = model.ds_transform.apply(to_days(list(ds)))
+    mu, sigma, _, info = model._eng().predict(model.programs(), t, y, t_new, noise_on_new)
+    bad = np.flatnonzero(info)
+    if bad.size:
+        raise PosDefException(int(info[bad[0]]), int(bad[0]))
+    s = model.y_transform.slope
+    means = (mu - model.y_transform.intercept) / s
+    covs = sigma / (s * s)
+    w, _ = _normalized_weights(model)
+    if distributed.world()[1] > 1:   # every rank returns the full mixture
+        means = distributed.all_gather_rows(means)
+        covs = distributed.all_gather_rows(covs.reshape(covs.shape[0], -1)).reshape(
+            (-1,) + covs.shape[1:])
+        w = distributed.all_gather_rows(w[:, None])[:, 0]
+    return MixtureMVN(means, covs, w, model.rng)

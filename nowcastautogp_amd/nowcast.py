@@ -1,0 +1,185 @@
+"""The two call sites of the hot path, mirrored: ``make_and_fit_model`` (reference
+src/make_and_fit_model.jl:98-113) and ``forecast`` / ``forecast_with_nowcasts`` (reference
+src/forecasting.jl:142-280), plus the small containers their signatures need (``TData``,
+``create_transformed_data``, ``create_nowcast_data``: reference src/TData.jl:46-74,
+src/create_nowcast_data.jl:27-76).  Same names, argument meaning and error behaviour, so the
+reference's shape / assertion tests read the same against this module (tests/test_mirror_*.py).
+
+What is different by design: ``forecast_with_nowcasts`` does not fan scenarios out as tasks.  On
+the default path (``n_mcmc = n_hmc = 0``, ``forecast_n_hmc = None``) all scenarios share the
+appended dates and K does not depend on y, so ONE batched call (``ngp_nowcast_batch``) factorises
+every particle once and returns every scenario's weight update and predictive mean; with
+refinement requested it falls back to the reference's per-scenario loop on cloned models.
+"""
+from __future__ import annotations
+
+import copy
+import warnings
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import autogp, gp
+from .autogp import GPModel
+
+GPConfig = gp.GPConfig
+
+__all__ = ["TData", "GPModel", "GPConfig", "create_transformed_data", "make_and_fit_model",
+           "forecast", "forecast_with_nowcasts", "create_nowcast_data"]
+
+
+class TData:
+    """(ds, y, values): dates, transformed targets, original values (reference src/TData.jl)."""
+
+    def __init__(self, ds, values, *, transformation: Callable):
+        ds, values = list(ds), list(values)
+        assert len(ds) == len(values), "length of `ds` should match length of `values`"
+        vals = np.asarray(values)
+        y = np.asarray([transformation(v) for v in vals.tolist()])
+        dtype = np.result_type(y.dtype, vals.dtype)
+        self.ds = ds
+        self.y = y.astype(dtype)
+        self.values = vals.astype(dtype)
+
+
+def create_transformed_data(ds, values, *, transformation: Callable) -> TData:
+    return TData(list(ds), list(values), transformation=transformation)
+
+
+def create_nowcast_data(nowcasts, dates, *, transformation: Callable = lambda y: y) -> List[TData]:
+    """vector-of-vectors, or a matrix whose COLUMNS are scenarios (reference
+    src/create_nowcast_data.jl:71-76)."""
+    if isinstance(nowcasts, np.ndarray) and nowcasts.ndim == 2:
+        nowcasts = [nowcasts[:, j] for j in range(nowcasts.shape[1])]
+    nowcasts = list(nowcasts)
+    dates = list(dates)
+    assert all(len(v) == len(dates) for v in nowcasts), \
+        "Length of each nowcast must match length of dates"
+    assert len(nowcasts) > 0, "nowcasts must not be empty"
+    first = len(nowcasts[0])
+    assert all(len(v) == first for v in nowcasts), \
+        "All vectors in nowcasts must have the same length"
+    return [create_transformed_data(dates, v, transformation=transformation) for v in nowcasts]
+
+
+def _stabilize_for_fit(y, *, flat_threshold: float = 1.0e-3, rng=None):
+    """Jitter a near-constant series so the GP covariance stays positive definite (reference
+    src/make_and_fit_model.jl:37-47)."""
+    y = np.asarray(y, dtype=np.float64)
+    n = y.size
+    if n <= 1:
+        return y
+    scale = abs(y.sum() / n) + 1
+    rel_range = (y.max() - y.min()) / scale
+    if rel_range >= flat_threshold:
+        return y
+    sigma = flat_threshold * scale
+    warnings.warn(f"Near-constant series (relative range {rel_range} < {flat_threshold}); adding "
+                  f"jitter (sigma = {sigma}) so the GP covariance stays positive-definite (issue #51).")
+    rng = rng or np.random.default_rng()
+    return y + sigma * rng.standard_normal(n)
+
+
+_REQUIRED = object()
+
+
+def make_and_fit_model(data: TData, *, n_particles: int = 1, smc_data_proportion: float = 0.1,
+                       flat_threshold: float = 1.0e-3, config: Optional[GPConfig] = None,
+                       n_mcmc=_REQUIRED, n_hmc=_REQUIRED, engine=None, seed=None, **kwargs):
+    if n_mcmc is _REQUIRED or n_hmc is _REQUIRED:
+        # fit_smc! requires both (UndefKeywordError in the reference, test/test_gpconfig.jl:42)
+        raise TypeError("make_and_fit_model() missing required keyword arguments n_mcmc and n_hmc "
+                        "(forwarded to fit_smc)")
+    config = config if config is not None else GPConfig()
+    n_train = len(data.y)
+    y_fit = _stabilize_for_fit(data.y, flat_threshold=flat_threshold,
+                               rng=np.random.default_rng(seed))
+    model = GPModel(data.ds, y_fit, n_particles=n_particles, config=config, engine=engine,
+                    seed=seed)
+    effective = max(smc_data_proportion, 1.0 / n_train)
+    schedule = autogp.Schedule.linear_schedule(n_train, effective)
+    autogp.fit_smc(model, schedule=schedule, n_mcmc=n_mcmc, n_hmc=n_hmc, **kwargs)
+    return model
+
+
+def _apply(inv_transformation: Callable, a: np.ndarray) -> np.ndarray:
+    return np.vectorize(inv_transformation, otypes=[np.float64])(a)
+
+
+def forecast(model: GPModel, forecast_dates, forecast_draws: int, *,
+             inv_transformation: Callable = lambda y: y,
+             forecast_n_hmc: Optional[int] = None) -> np.ndarray:
+    """Matrix (len(forecast_dates), forecast_draws) of samples (reference src/forecasting.jl:142-188)."""
+    dates = list(forecast_dates)
+    if forecast_n_hmc is None:
+        draws = autogp.predict_mvn(model, dates).rand(int(forecast_draws))
+    else:
+        draws = np.empty((len(dates), int(forecast_draws)))
+        for i in range(int(forecast_draws)):
+            autogp.mcmc_parameters(model, forecast_n_hmc)
+            draws[:, i] = autogp.predict_mvn(model, dates).rand()
+    return _apply(inv_transformation, draws)
+
+
+def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forecast_dates,
+                           forecast_draws_per_nowcast: int, *,
+                           inv_transformation: Callable = lambda y: y, n_mcmc: int = 0,
+                           n_hmc: int = 0, ess_threshold: float = 0.0,
+                           forecast_n_hmc: Optional[int] = None, verbose: bool = False) -> np.ndarray:
+    assert len(nowcasts) > 0, "nowcasts vector must not be empty"
+    assert not (n_mcmc > 0 and n_hmc == 0), \
+        "If n_mcmc > 0, n_hmc must also be > 0 for MCMC refinement"
+    assert 0.0 <= ess_threshold <= 1.0, "ess_threshold must be between 0 and 1"
+    assert forecast_n_hmc is None or forecast_n_hmc > 0, "forecast_n_hmc must be > 0 if specified"
+    dates = list(forecast_dates)
+    draws = int(forecast_draws_per_nowcast)
+    same_dates = all(list(nc.ds) == list(nowcasts[0].ds) for nc in nowcasts)
+    single = autogp.distributed.world()[1] == 1
+    if n_mcmc == 0 and n_hmc == 0 and forecast_n_hmc is None and same_dates and single:
+        return _forecast_with_nowcasts_batched(base_model, nowcasts, dates, draws,
+                                               inv_transformation, ess_threshold)
+    base = base_model.to_dict()
+    results = []
+    for nc in nowcasts:   # the reference's per-scenario task, sequential here
+        m = GPModel.from_dict(copy.deepcopy(base), engine=base_model.engine)
+        autogp.add_data(m, nc.ds, nc.y)
+        autogp.maybe_resample(m, ess_threshold * autogp.num_particles(m))
+        if n_mcmc > 0 and n_hmc > 0:
+            autogp.mcmc_structure(m, n_mcmc, n_hmc)
+        elif n_mcmc == 0 and n_hmc > 0:
+            autogp.mcmc_parameters(m, n_hmc)
+        results.append(forecast(m, dates, draws, inv_transformation=inv_transformation,
+                                forecast_n_hmc=forecast_n_hmc))
+        if verbose:
+            print(f"Nowcast scenarios: {len(results)}/{len(nowcasts)}")
+    return np.hstack(results)
+
+
+def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transformation,
+                                    ess_threshold):
+    """All scenarios in one engine call: one factorisation per particle (src/forecasting.jl:246-268
+    with n_mcmc = n_hmc = 0)."""
+    t, y = model._obs()
+    t_add = model.ds_transform.apply(autogp.to_days(list(nowcasts[0].ds)))
+    y_add = np.stack([model.y_transform.apply(np.asarray(nc.y, dtype=np.float64))
+                      for nc in nowcasts])
+    t_new = model.ds_transform.apply(autogp.to_days(dates))
+    out = model._eng().nowcast(model.programs(), t, y, t_add, y_add, t_new, True)
+    bad = np.flatnonzero(out["info"])
+    if bad.size:
+        raise autogp.PosDefException(int(out["info"][bad[0]]), int(bad[0]))
+    s, b = model.y_transform.slope, model.y_transform.intercept
+    covs = out["sigma"] / (s * s)
+    P = len(model.particles)
+    rng = model.rng
+    res = np.empty((len(dates), len(nowcasts) * draws))
+    for sc in range(len(nowcasts)):
+        logw = model.log_weights + (out["logml_full"][:, sc] - out["logml_base"])
+        from . import _lib
+        w, ess, _ = _lib.weights_normalize(logw)
+        if ess < ess_threshold * P:          # maybe_resample!: ancestors ~ w, weights -> uniform
+            anc = rng.choice(P, size=P, p=w)
+            w = np.bincount(anc, minlength=P) / P
+        mix = autogp.MixtureMVN((out["mu"][:, sc, :] - b) / s, covs, w, rng)
+        res[:, sc * draws:(sc + 1) * draws] = mix.rand(draws)
+    return _apply(inv_transformation, res)
