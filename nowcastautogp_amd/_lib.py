@@ -16,7 +16,7 @@ from ._abi import (KernelArray, NgpKernel, NgpProfile, NgpSpec, as_f64, c_double
                    dptr, iptr)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libngp.so")
+LIB_PATH = os.environ.get("NGP_LIB") or os.path.join(_HERE, "libngp.so")  # NGP_LIB: A/B builds
 
 KERNEL_CLASSES = ("chol_col", "chol_diag", "gram", "epilogue", "fill", "grad", "r6", "r7")
 

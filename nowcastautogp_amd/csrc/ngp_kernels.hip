@@ -815,31 +815,31 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// chol_col, LDS-staged form (the production path; the direct-load kernel above remains for the
-// single diag-ahead tile).  Same math and the same FAT / THIN / FULL schedule, different data
-// movement:
-//   * the workgroup loads each 16-deep k-chunk of its operand rows cooperatively with full-line
-//     global loads (8 rows x 128 B per wave-instruction instead of 16 half-lines), once, into a
-//     padded LDS tile (row stride 136 B: the 16 rows of a fragment land on distinct banks);
-//   * two LDS buffers, one barrier per chunk: chunk c+1 travels HBM -> registers while chunk c is
-//     multiplied, and is written to the other buffer after the MFMAs;
-//   * the three rotated copies of every B fragment that the 4x4x4 MFMA form needs come from LDS by
-//     address (row (n' + 4r) mod 16) instead of DPP moves: the k-loop is ds_read_b64 + MFMA only.
-//   FAT steps only (they carry all the long k-loops): A panel = rows of blocks j and j+1 (128),
-//   B = 2 row tiles (128); wave = (tile, column).  THIN / FULL steps use the direct-load kernel.
-// ---------------------------------------------------------------------------------------
-// bytes per staged row: 16 doubles + 8 B pad = 34 dwords.  hipcc fuses the k-adjacent operand reads
-// into ds_read2_b64 (banked mod 32 per 16-lane group): the 16 rows of a fragment then need a row
-// stride of 2*odd dwords to cover all 32 banks once (a 144-B stride measured 45 % conflict cycles).
-constexpr int LDS_ROWB = 136;
-constexpr int LDS_KC = 16;
+constexpr int LDS_KC = 16;   // k-depth of one staged chunk
 
-__global__ __launch_bounds__(256, 2) void chol_col_lds_kernel(JobGeom g, ChunkPtrs p, int Bc,
-                                                              ColStep st) {
-    constexpr int AROWS = 128, BROWS = 128, ROWS = AROWS + BROWS;
-    constexpr int STAGE = ROWS * LDS_ROWB;       // bytes per buffer
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+// ---------------------------------------------------------------------------------------
+// chol_col FAT step (the production path; carries all the long k-loops).  Same math and the
+// same FAT / THIN / FULL schedule as the direct-load kernel above, different data movement:
+//   * the workgroup stages each 16-deep k-chunk of its operand rows ONCE into LDS: A panel = rows
+//     of blocks j and j+1 (128), B = 2 row tiles (128); wave = (tile, column);
+//   * two LDS buffers, one barrier per chunk: chunk c+1 is in flight while chunk c is multiplied;
+//   * the three rotated copies of every B fragment that the 4x4x4 MFMA form needs come from LDS by
+//     address (row (n' + 4r) mod 16) instead of DPP moves: the k-loop is ds_read_b64 + MFMA only;
+//   * the operand rows go HBM -> LDS directly (buffer_load_dwordx4 ... lds: no VGPR round trip, no
+//     ds_write).  A register-staged predecessor (padded 136-B rows, ds_write2_b64) measured 11 %
+//     slower on the same box.  An LDS-DMA instruction writes 1 KiB contiguously (8 rows x 128 B here), so rows cannot
+// be padded; bank conflicts are removed by an XOR swizzle applied on the SOURCE address
+// (slot p of row r holds the 16-byte piece p ^ ((r>>1)&7)) and again on the read address
+// (guide rule: linear destination + swizzled source + the same swizzle on the read).  The
+// swizzled read address is not affine in the k-step, so each (fragment, k-step) has its own
+// address register — which also keeps hipcc from fusing the reads into ds_read2_b64 (banked
+// mod 32, inherently 2-way conflicting on 16-byte-granular layouts).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkPtrs p, int Bc,
+                                                               ColStep st) {
+    constexpr int ROWS = 256, ROWB = 128, STAGE = ROWS * ROWB;   // 32 KiB per buffer
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    typedef __attribute__((address_space(3))) void *lds_ptr;
 
     const int wg = blockIdx.x;
     const int xcd = wg & 7, idx = wg >> 3;       // blocks b and b+8 share an XCD (speed only)
@@ -848,8 +848,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_lds_kernel(JobGeom g, ChunkPt
     if (item >= Bc) return;                      // whole workgroup, before any barrier
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ltile = wave >> 1;                 // which of the workgroup's two row tiles
-    const int col = wave & 1;                    // 0: column j, 1: column j+1 (partial)
+    const int ltile = wave >> 1, col = wave & 1;
     const int tile0 = grp * 2;
     const int tile = tile0 + ltile;
     const bool valid = tile < st.ntiles;
@@ -860,28 +859,51 @@ __global__ __launch_bounds__(256, 2) void chol_col_lds_kernel(JobGeom g, ChunkPt
     const int kmax = j * NB;
     const int r16 = lane & 15, q = lane >> 4;
     auto tile_row0 = [&](int t) -> long {
-        if (t >= st.ntiles) t = st.ntiles - 1;   // out-of-range slot stages a valid tile, computes nothing
+        if (t >= st.ntiles) t = st.ntiles - 1;
         return (t < st.nmain) ? (long)(j + 1 + t) * NB : (long)g.n0 + (long)(t - st.nmain) * NB;
     };
-    // ---- staging: thread -> (row tid>>3 (+32 per step), 16-B piece tid&7).  Buffer loads: one
-    //      descriptor for the item, ONE per-thread byte offset, everything else scalar
-    //      (region base, row step, k) — keeps the address arithmetic out of the VGPR file.
+    // ---- staging: wave w fills stage rows [64w, 64w+64): waves 0,1 the A panel (blocks j, j+1),
+    //      waves 2,3 the two row tiles; instruction i covers rows 8i..8i+7 (lane>>3) x 8 pieces
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         Lit, 0, (int)(g.item_stride * (long)sizeof(double)), 0x00020000);
-    const unsigned offA = (unsigned)((long)j * NB * ld * 8);
-    const unsigned offB0 = (unsigned)(tile_row0(tile0) * ld * 8);
-    const unsigned offB1 = (unsigned)(tile_row0(tile0 + 1) * ld * 8);
-    const unsigned step32 = (unsigned)(32 * ld * 8);
-    const unsigned voff = (unsigned)(((tid >> 3) * ld + 2 * (tid & 7)) * 8);
-    const unsigned lwr = (unsigned)((tid >> 3) * LDS_ROWB + (tid & 7) * 16);
-    // ---- operand read addresses (bytes inside a stage)
-    const unsigned a_base = (unsigned)((64 * col + r16) * LDS_ROWB + q * 8);
-    unsigned b_base[4];
+    long src_row0;
+    if (wave < 2) src_row0 = (long)j * NB + 64 * wave;
+    else src_row0 = tile_row0(tile0 + (wave - 2));
+    const unsigned soff_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(src_row0 * ld * 8));
+    const unsigned row_step8 = (unsigned)(8 * ld * 8);
+    // piece fetched by this lane = (lane&7) ^ key(row), key = (row>>1)&7 = (4i + (lane>>4)) & 7
+    const unsigned voff_even = (unsigned)(((lane >> 3) * ld + 2 * ((lane & 7) ^ ((lane >> 4) & 7))) * 8);
+    const unsigned voff_odd = (unsigned)(((lane >> 3) * ld + 2 * ((lane & 7) ^ ((4 + (lane >> 4)) & 7))) * 8);
+    auto stage = [&](int buf, int k) {
+        const unsigned kb = (unsigned)k * 8u;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        b_base[r] = (unsigned)((AROWS + 64 * ltile + ((r16 + 4 * r) & 15)) * LDS_ROWB + q * 8);
+        for (int i = 0; i < 8; ++i) {
+            lds_ptr dst = (lds_ptr)(smem + buf * STAGE + (64 * wave + 8 * i) * ROWB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, (i & 1) ? voff_odd : voff_even,
+                                                     soff_base + i * row_step8 + kb, 0, 0);
+        }
+    };
+    // ---- operand read addresses: row * 128 + ((piece ^ key) * 16) + (k&1) * 8, piece = 2s + (q>>1)
+    unsigned a_addr[4], b_addr[4][4];
+    {
+        const int arow = 64 * col + r16;
+        const int akey = (r16 >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            a_addr[s] = (unsigned)(arow * ROWB + (((2 * s + (q >> 1)) ^ akey) << 4) + (q & 1) * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = (r16 + 4 * r) & 15;
+            const int brow = 128 + 64 * ltile + rr;
+            const int bkey = (rr >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                b_addr[r][s] =
+                    (unsigned)(brow * ROWB + (((2 * s + (q >> 1)) ^ bkey) << 4) + (q & 1) * 8);
+        }
+    }
 
-    double acc4[4][4][4];  // [jt][it][r]: block-diagonal r of S' tile (jt, it), see mfma16_as_4
+    double acc4[4][4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -889,66 +911,36 @@ __global__ __launch_bounds__(256, 2) void chol_col_lds_kernel(JobGeom g, ChunkPt
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
 
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    auto gload = [&](f64x2 (&stg)[8], int k) {
-        const unsigned kb = (unsigned)k * 8u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, offA + i * step32 + kb, 0);
-            stg[i] = __builtin_bit_cast(f64x2, v);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, offB0 + i * step32 + kb, 0);
-            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, offB1 + i * step32 + kb, 0);
-            stg[4 + i] = __builtin_bit_cast(f64x2, v0);
-            stg[6 + i] = __builtin_bit_cast(f64x2, v1);
-        }
-    };
-    auto lstore = [&](char *buf, const f64x2 (&stg)[8]) {   // rows are 8-B aligned only
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            double *d = reinterpret_cast<double *>(buf + lwr + i * 32 * LDS_ROWB);
-            d[0] = stg[i].x;
-            d[1] = stg[i].y;
-        }
-    };
-
     const int nchunks = (kmax - st.k0) / LDS_KC;
     if (nchunks > 0) {
-        f64x2 stg[8];
-        gload(stg, st.k0);
-        lstore(smem, stg);
-        __syncthreads();
+        stage(0, st.k0);
+        __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
         for (int c = 0; c < nchunks; ++c) {
-            const char *buf = smem + (c & 1) * STAGE;
-            if (c + 1 < nchunks && !(st.dbg & 1)) gload(stg, st.k0 + (c + 1) * LDS_KC);
-            const char *pa = buf + a_base;
-            const char *pb0 = buf + b_base[0], *pb1 = buf + b_base[1];
-            const char *pb2 = buf + b_base[2], *pb3 = buf + b_base[3];
+            const int cur = c & 1;
+            if (c + 1 < nchunks && !(st.dbg & 1)) stage(cur ^ 1, st.k0 + (c + 1) * LDS_KC);
+            const char *buf = smem + cur * STAGE;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 double a[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    a[u] = *reinterpret_cast<const double *>(pa + u * 16 * LDS_ROWB + s * 32);
+                    a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 16 * ROWB);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     Rot4 br;
-                    br.r0 = *reinterpret_cast<const double *>(pb0 + it * 16 * LDS_ROWB + s * 32);
-                    br.r1 = *reinterpret_cast<const double *>(pb1 + it * 16 * LDS_ROWB + s * 32);
-                    br.r2 = *reinterpret_cast<const double *>(pb2 + it * 16 * LDS_ROWB + s * 32);
-                    br.r3 = *reinterpret_cast<const double *>(pb3 + it * 16 * LDS_ROWB + s * 32);
+                    br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 16 * ROWB);
+                    br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 16 * ROWB);
+                    br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * 16 * ROWB);
+                    br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * 16 * ROWB);
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[jt], br);
                 }
             }
-            if (c + 1 < nchunks && !(st.dbg & 1)) lstore(smem + ((c + 1) & 1) * STAGE, stg);
             if (!(st.dbg & 2)) __syncthreads();
         }
     }
     if (!valid) return;
-    if (st.dbg & 4) {   // keep the accumulators alive, skip the epilogue
+    if (st.dbg & 4) {   // timing ablation: keep the accumulators alive, skip the epilogue
         double sum = 0.0;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
@@ -963,7 +955,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_lds_kernel(JobGeom g, ChunkPt
     double *Lr = Lit + tile_row0(tile) * ld;
     const double *Lj = Lit + (long)(j + col) * NB * ld;
     if (col) {
-        subtract_in_place(Lr, ld, (j + 1) * NB, acc4, r16, q);   // column j+1, partial sum
+        subtract_in_place(Lr, ld, (j + 1) * NB, acc4, r16, q);
     } else {
         const double *dinv = p.dinv + (long)item * (NB / TB) * (TB * TB);
         solve_and_store(acc4, Lr, Lj, dinv, ld, kmax, r16, q);
@@ -1447,7 +1439,7 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
     const int bpad = (Bc + 7) / 8 * 8;
     if (mode == COL_FAT) {
         st.groups = (st.ntiles + 1) / 2;
-        hipLaunchKernelGGL(chol_col_lds_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p, Bc,
+        hipLaunchKernelGGL(chol_col_glds_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p, Bc,
                            st);
         (void)ahead;
     } else {
