@@ -837,7 +837,12 @@ constexpr int LDS_KC = 16;   // k-depth of one staged chunk
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                                ColStep st) {
-    constexpr int ROWS = 256, ROWB = 128, STAGE = ROWS * ROWB;   // 32 KiB per buffer
+    // 32 LDS-DMA blocks (8 rows x 128 B) per buffer, each followed by a 128-B gap: row groups of
+    // a fragment are then 2304 B apart, which hipcc cannot fuse into ds_read2st64_b64 (offsets
+    // must be multiples of 512 B; fused reads bank mod 32 and measured 50 % conflict cycles),
+    // and (bit3 ^ bit0, bits 3..1) of the row index still select distinct bank groups.
+    constexpr int ROWB = 128, BLKB = 8 * ROWB + 128, STAGE = 32 * BLKB;   // 36 KiB per buffer
+    auto row_off = [](int row) { return (row >> 3) * BLKB + (row & 7) * ROWB; };
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     typedef __attribute__((address_space(3))) void *lds_ptr;
 
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
         const unsigned kb = (unsigned)k * 8u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            lds_ptr dst = (lds_ptr)(smem + buf * STAGE + (64 * wave + 8 * i) * ROWB);
+            lds_ptr dst = (lds_ptr)(smem + buf * STAGE + (8 * wave + i) * BLKB);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, (i & 1) ? voff_odd : voff_even,
                                                      soff_base + i * row_step8 + kb, 0, 0);
         }
@@ -890,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
         const int akey = (r16 >> 1) & 7;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-            a_addr[s] = (unsigned)(arow * ROWB + (((2 * s + (q >> 1)) ^ akey) << 4) + (q & 1) * 8);
+            a_addr[s] = (unsigned)(row_off(arow) + (((2 * s + (q >> 1)) ^ akey) << 4) + (q & 1) * 8);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = (r16 + 4 * r) & 15;
@@ -899,7 +904,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 b_addr[r][s] =
-                    (unsigned)(brow * ROWB + (((2 * s + (q >> 1)) ^ bkey) << 4) + (q & 1) * 8);
+                    (unsigned)(row_off(brow) + (((2 * s + (q >> 1)) ^ bkey) << 4) + (q & 1) * 8);
         }
     }
 
@@ -924,14 +929,14 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
                 double a[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 16 * ROWB);
+                    a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 2 * BLKB);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     Rot4 br;
-                    br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 16 * ROWB);
-                    br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 16 * ROWB);
-                    br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * 16 * ROWB);
-                    br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * 16 * ROWB);
+                    br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 2 * BLKB);
+                    br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 2 * BLKB);
+                    br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * 2 * BLKB);
+                    br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * 2 * BLKB);
 #pragma unroll
                     for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[jt], br);
                 }
