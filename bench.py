@@ -180,8 +180,12 @@ def main():
                        "items_per_gpu": B, "parallelism": f"particles sharded x{world}"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "chol_col_kernel (v_mfma_f64_16x16x4_f64 trailing update + in-register "
-                          "triangular solve)",
+                "kernel": "chol_col (chol_col_glds_kernel FAT steps + chol_col_kernel THIN steps: "
+                          "v_mfma_f64_4x4x4_4b_f64 trailing update, LDS-DMA staged operands, "
+                          "in-register 64-wide triangular solve)",
+                "measured_issue_ceiling": {"v_mfma_f64_4x4x4_4b_f64": 75.0,
+                                           "v_mfma_f64_16x16x4_f64": 49.5, "unit": "TFLOP/s",
+                                           "source": "profiles/r01/ubench_mfma*.log"},
                 "achieved": ach,
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

@@ -172,6 +172,11 @@ struct ngp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // diag-ahead tiles run beside the main schedule
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // second lane: with several chunks in a job, alternate chunks run on a second stream so the
+    // latency-bound chol_diag / HBM-write-bound fill of one chunk overlap the MFMA-bound chol_col
+    // of the other
+    hipStream_t stream2 = nullptr, side2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_lane2 = nullptr;
     ngp_spec spec{};
     std::mutex mu;
     bool profiling = false;
@@ -266,6 +271,14 @@ extern "C" ngp_status ngp_ctx_create(int32_t device, ngp_ctx **out) {
         delete c;
         return NGP_ERR_NO_DEVICE;
     }
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_lane2, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return NGP_ERR_NO_DEVICE;
+    }
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->mem_cap = (size_t)(0.6 * (double)fr);
     else c->mem_cap = (size_t)8 << 30;
@@ -283,6 +296,11 @@ extern "C" void ngp_ctx_destroy(ngp_ctx *c) {
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
+    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+    if (c->ev_lane2) (void)hipEventDestroy(c->ev_lane2);
     delete c;
 }
 
@@ -377,8 +395,17 @@ struct EventTimer {  // HIP events on the launch stream, resolved after the job'
 // Block columns in pairs: a FAT step finishes column jj and pre-accumulates column jj+1 (and,
 // on a side stream, the diagonal tile of jj+2) from the same streamed rows; the THIN step that
 // follows only adds k in [64 (jj-1), 64 jj).  See chol_col_lds_kernel.
-void factor_chunk(ngp_ctx *c, const JobGeom &g, const ChunkPtrs &p, int bc, EventTimer &tm) {
-    hipStream_t s = c->stream;
+struct Lane {
+    hipStream_t main, side;
+    hipEvent_t fork, join;
+};
+inline Lane lane_of(ngp_ctx *c, int i) {
+    return i == 0 ? Lane{c->stream, c->side, c->ev_fork, c->ev_join}
+                  : Lane{c->stream2, c->side2, c->ev_fork2, c->ev_join2};
+}
+
+void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p, int bc, EventTimer &tm) {
+    hipStream_t s = ln.main;
     const double nrows_aux = (double)g.naux;
     bool ahead_pending = false;
     for (int jj = 0; jj < g.nb0; ++jj) {
@@ -395,7 +422,7 @@ void factor_chunk(ngp_ctx *c, const JobGeom &g, const ChunkPtrs &p, int bc, Even
         // the diag-ahead tile (jj, jj) was launched on the side stream at step jj-2, beside
         // diag(jj-1) / col(jj-1); chol_diag(jj) is its only consumer
         if (ahead_pending && (jj % 2 == 0)) {
-            (void)hipStreamWaitEvent(s, c->ev_join, 0);
+            (void)hipStreamWaitEvent(s, ln.join, 0);
             ahead_pending = false;
         }
         tm.run(1, bc * ((double)NB * NB * kd + (double)NB * NB * NB / 3.0),
@@ -412,15 +439,15 @@ void factor_chunk(ngp_ctx *c, const JobGeom &g, const ChunkPtrs &p, int bc, Even
         tm.run(0, bc * fl, bc * by,
                [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, ahead, s); });
         if (ahead && jj > 0) {
-            (void)hipEventRecord(c->ev_fork, s);
-            (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
-            launch_diag_ahead(g, p, bc, jj, c->side);
-            (void)hipEventRecord(c->ev_join, c->side);
+            (void)hipEventRecord(ln.fork, s);
+            (void)hipStreamWaitEvent(ln.side, ln.fork, 0);
+            launch_diag_ahead(g, p, bc, jj, ln.side);
+            (void)hipEventRecord(ln.join, ln.side);
             ahead_pending = true;
         }
     }
     if (ahead_pending) {
-        (void)hipStreamWaitEvent(s, c->ev_join, 0);
+        (void)hipStreamWaitEvent(s, ln.join, 0);
         ahead_pending = false;
     }
 }
@@ -569,49 +596,75 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     hipStream_t s = c->stream;
     const DevSpec sp = dev_spec(c->spec);
     EventTimer tm(c->profiling, s);
+    EventTimer tm2(c->profiling, c->stream2);
     HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)g.B, s));
     HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
-    void *Lbuf = nullptr, *dinv = nullptr, *tab = nullptr, *sig = nullptr;
+    void *Lbuf[2] = {nullptr, nullptr}, *dinv[2] = {nullptr, nullptr};
+    void *tab[2] = {nullptr, nullptr}, *sig[2] = {nullptr, nullptr};
+    auto release_all = [&] {
+        for (int l = 0; l < 2; ++l) {
+            c->release(Lbuf[l]); c->release(dinv[l]); c->release(tab[l]); c->release(sig[l]);
+        }
+    };
     if (g.n0 > 0) {
         const size_t tab_bytes = g.lattice ? sizeof(double) * (size_t)g.maxstat * g.R : 0;
         const size_t sig_bytes = g.lattice ? sizeof(double) * (size_t)g.maxcp * g.npts : 0;
         const size_t item_bytes = (size_t)g.item_stride * sizeof(double) + tab_bytes + sig_bytes;
         int Bc = (int)std::min<size_t>((size_t)g.B, std::max<size_t>(1, c->mem_cap / item_bytes));
+        // Optional second lane (NGP_LANES=2): each lane owns a slab of half the chunk size and takes
+        // alternate chunks, so chol_diag / fill of one chunk overlap chol_col of the other.
+        // Measured on the headline step: 898-900 ms vs 905-912 ms on one lane (chol_col already
+        // fills the register file), at the price of overlapping per-kernel event timings — so it is
+        // off by default and the roofline figures are always taken on one lane.
+        static const int lanes_env = getenv("NGP_LANES") ? atoi(getenv("NGP_LANES")) : 1;
+        const int nl = (lanes_env >= 2 && g.B >= 4096) ? 2 : 1;
+        if (nl == 2) Bc = std::max(1, std::min(Bc / 2, (g.B + 1) / 2));
         const size_t l_bytes = (size_t)g.item_stride * sizeof(double);
-        ngp_status st = c->alloc(&Lbuf, l_bytes * (size_t)Bc);
-        while (st && Bc > 1) {  // back off if the device is fuller than expected
-            Bc = (Bc + 1) / 2;
-            st = c->alloc(&Lbuf, l_bytes * (size_t)Bc);
+        ngp_status st = NGP_OK;
+        for (int l = 0; l < nl && !st; ++l) {
+            st = c->alloc(&Lbuf[l], l_bytes * (size_t)Bc);
+            if (!st) st = c->alloc(&dinv[l], sizeof(double) * (size_t)Bc * (NB / TB) * TB * TB);
+            if (!st && g.lattice) st = c->alloc(&tab[l], tab_bytes * (size_t)Bc);
+            if (!st && g.lattice) st = c->alloc(&sig[l], sig_bytes * (size_t)Bc);
         }
-        if (st) return st;
-        st = c->alloc(&dinv, sizeof(double) * (size_t)Bc * (NB / TB) * TB * TB);
-        if (!st && g.lattice) st = c->alloc(&tab, tab_bytes * (size_t)Bc);
-        if (!st && g.lattice) st = c->alloc(&sig, sig_bytes * (size_t)Bc);
-        if (st) { c->release(Lbuf); c->release(dinv); c->release(tab); c->release(sig); return st; }
+        if (st) { release_all(); return st; }
+        if (nl == 2) {   // lane 2 starts after the memsets queued on lane 1
+            (void)hipEventRecord(c->ev_lane2, s);
+            (void)hipStreamWaitEvent(c->stream2, c->ev_lane2, 0);
+        }
         const double nrows_aux = (double)g.naux;
-        for (int b0 = 0; b0 < g.B; b0 += Bc) {
+        int chunk = 0;
+        for (int b0 = 0; b0 < g.B; b0 += Bc, ++chunk) {
             const int bc = std::min(Bc, g.B - b0);
+            const int l = chunk % nl;
+            const Lane ln = lane_of(c, l);
+            EventTimer &t = l ? tm2 : tm;
             ChunkPtrs p{};
-            p.L = (double *)Lbuf;
-            p.dinv = (double *)dinv;
+            p.L = (double *)Lbuf[l];
+            p.dinv = (double *)dinv[l];
             p.progs = j->progs + b0;
             p.t0 = j->t0;
             p.taux = j->taux;
             p.y0 = j->y0 + (g.y_shared ? 0 : (int64_t)b0 * g.n0);
             p.logdet = j->logdet + b0;
             p.info = j->info + b0;
-            p.tab = (double *)tab;
-            p.sig = (double *)sig;
+            p.tab = (double *)tab[l];
+            p.sig = (double *)sig[l];
             p.qpts = j->qpts;
             if (g.lattice)
-                tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
+                t.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, ln.main); });
             const double fill_elems =
                 (double)bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0);
-            tm.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, s); });
-            factor_chunk(c, g, p, bc, tm);
-            tm.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0, [&] {
-                launch_gram(g, (const double *)Lbuf, j->G + (int64_t)b0 * g.naux * g.naux, bc, s);
+            t.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, ln.main); });
+            factor_chunk(ln, g, p, bc, t);
+            t.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0, [&] {
+                launch_gram(g, (const double *)Lbuf[l], j->G + (int64_t)b0 * g.naux * g.naux, bc,
+                            ln.main);
             });
+        }
+        if (nl == 2) {   // join lane 2 before the epilogue
+            (void)hipEventRecord(c->ev_lane2, c->stream2);
+            (void)hipStreamWaitEvent(s, c->ev_lane2, 0);
         }
     }
     EpiPtrs e{};
@@ -632,10 +685,8 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipGetLastError();
     tm.resolve(c->prof);
-    c->release(Lbuf);
-    c->release(dinv);
-    c->release(tab);
-    c->release(sig);
+    tm2.resolve(c->prof);
+    release_all();
     if (err != hipSuccess) return (ngp_status)err;
     j->ran = true;
     return NGP_OK;
@@ -904,7 +955,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
         tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + (double)g.naux * g.n0),
                [&] { launch_fill(g, p, bc, sp, s); });
-        factor_chunk(c, g, p, bc, tm);
+        factor_chunk(lane_of(c, 0), g, p, bc, tm);
         const double n3 = (double)g.n0 * g.n0 * g.n0;
         tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
             launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
