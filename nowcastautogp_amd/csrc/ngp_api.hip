@@ -623,7 +623,7 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
         ngp_status st = NGP_OK;
         for (int l = 0; l < nl && !st; ++l) {
             st = c->alloc(&Lbuf[l], l_bytes * (size_t)Bc);
-            if (!st) st = c->alloc(&dinv[l], sizeof(double) * (size_t)Bc * (NB / TB) * TB * TB);
+            if (!st) st = c->alloc(&dinv[l], sizeof(double) * (size_t)Bc * NB * NB);
             if (!st && g.lattice) st = c->alloc(&tab[l], tab_bytes * (size_t)Bc);
             if (!st && g.lattice) st = c->alloc(&sig[l], sig_bytes * (size_t)Bc);
         }
@@ -918,7 +918,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         (g.lattice && (st = dalloc(&d_q, 4 * (size_t)g.n0))) ||
         (st = dalloc(&d_logdet, 8 * (size_t)B)) || (st = dalloc(&d_info, 4 * (size_t)B)) ||
         (st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
-        (st = dalloc(&d_dinv, 8 * (size_t)Bc * (NB / TB) * TB * TB)) ||
+        (st = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
         (g.lattice && ((st = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
                        (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)))) ||
         (st = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||

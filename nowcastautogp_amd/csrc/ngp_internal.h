@@ -64,7 +64,7 @@ struct JobGeom {
 
 struct ChunkPtrs {
     double       *L;      // [Bc][(n0 + naux_pad) x n0] factor + aux rows, row-major
-    double       *dinv;   // [Bc][NB/TB][TB x TB] diagonal-block inverses of the current step
+    double       *dinv;   // [Bc][64 strips x 64 lanes] L_jj^-1 of the current step, MFMA strip order
     const DevProgram *progs;  // [Bc] (already offset to the chunk)
     const double *t0;     // [n0]
     const double *taux;   // [da + m] times of the aux rows (appended then forecast)

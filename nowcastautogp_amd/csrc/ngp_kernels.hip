@@ -448,6 +448,7 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
     __shared__ double At[NB][NB + 1];
     __shared__ double Lt[NB][NB + 1];
     __shared__ double logs[NB];
+    __shared__ double red_scratch[TB * (TB + 1)];
     __shared__ int bad;
     const int item = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -578,7 +579,12 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
     }
     __syncthreads();
 
-    // ---- inverses of the four 16x16 diagonal blocks (column c of block b per thread)
+    // ---- M = L_jj^-1 (64 x 64, lower): the four 16x16 diagonal-block inverses by forward
+    //      substitution (column c of block b per thread), then the six off-diagonal tiles by block
+    //      recursion  M[ct][jt] = -M[ct][ct] (sum_{k=jt}^{ct-1} L[ct][k] M[k][jt]),  one tile at a
+    //      time over 256 threads.  At is free now and holds M.
+    for (int e = tid; e < NB * (NB + 1); e += 256) (&At[0][0])[e] = 0.0;
+    __syncthreads();
     if (tid < NB) {
         const int b = tid >> 4, c = tid & 15;
         double x[TB];
@@ -589,9 +595,40 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
             for (int pp = 0; pp < i; ++pp) sum -= Lt[TB * b + i][TB * b + pp] * x[pp];
             x[i] = sum / Lt[TB * b + i][TB * b + i];
         }
-        double *dv = p.dinv + ((long)item * (NB / TB) + b) * (TB * TB);
 #pragma unroll
-        for (int i = 0; i < TB; ++i) dv[i * TB + c] = x[i];
+        for (int i = 0; i < TB; ++i) At[TB * b + i][TB * b + c] = x[i];
+    }
+    __syncthreads();
+    {
+        double(*Ts)[TB + 1] = reinterpret_cast<double(*)[TB + 1]>(&red_scratch[0]);
+        const int ra = tid >> 4, cb = tid & 15;
+        for (int dist = 1; dist < NB / TB; ++dist)
+            for (int ct = dist; ct < NB / TB; ++ct) {
+                const int jt = ct - dist;
+                double t = 0.0;
+                for (int kt = jt; kt < ct; ++kt)
+#pragma unroll
+                    for (int pp = 0; pp < TB; ++pp)
+                        t += Lt[TB * ct + ra][TB * kt + pp] * At[TB * kt + pp][TB * jt + cb];
+                Ts[ra][cb] = t;
+                __syncthreads();
+                double mv = 0.0;
+#pragma unroll
+                for (int pp = 0; pp < TB; ++pp) mv -= At[TB * ct + ra][TB * ct + pp] * Ts[pp][cb];
+                At[TB * ct + ra][TB * jt + cb] = mv;
+                __syncthreads();
+            }
+    }
+    // strip order: strip (cb4, jt) is the A operand of v_mfma_f64_4x4x4 for output rows
+    // 4 cb4 .. 4 cb4 + 3 against the 16 columns of tile jt: lane l holds
+    // M[4 cb4 + (l & 3)][16 jt + 4 ((l >> 2) & 3) + (l >> 4)] — one coalesced 512-B load per strip
+    {
+        double *dv = p.dinv + (long)item * (NB * NB);
+        for (int e = tid; e < NB * NB; e += 256) {
+            const int strip = e >> 6, l = e & 63;
+            const int cb4 = strip >> 2, jt = strip & 3;
+            dv[e] = At[4 * cb4 + (l & 3)][16 * jt + 4 * ((l >> 2) & 3) + (l >> 4)];
+        }
     }
     // ---- write L_jj back (strict upper part zero)
     for (int e = tid; e < NB * NB; e += 256) {
@@ -743,6 +780,101 @@ __device__ __forceinline__ void solve_and_store(const double (*acc4)[4][4], doub
                 Lr[(long)(16 * it + r16) * ld + kmax + 16 * ct + q + 4 * s] = acc[ct][it][s];
 }
 
+// ---------------------------------------------------------------------------------------
+// Epilogue on the 4x4x4 register layout (no accumulator layout conversion, no 16x16x4 MFMA).
+//   acc4[jt][it][r] at lane l:  S'[jj = 16 jt + 4 ((l&15)>>2) + (l>>4)][i = 16 it + ((l&15) + 4r) & 15]
+// L_rj = C_rj L_jj^-T  <=>  X' = M C'  with the full inverse M = L_jj^-1 from chol_diag.  An MFMA
+// with A = strip (cb4, jt) of M and B = C'[jt][it][r] multiplies, in every lane group b, the 4x4
+// block of M against the row-block b of C' — a partial sum of X'[4 cb4 ..][i] over the rows
+// jj = 4b (mod 16).  The four partial sums of an element sit in four different (register, lane
+// group) pairs; three whole-register DPP rotations line them up and they are added in a fixed
+// order, written to a per-wave LDS tile and from there to HBM as full 512-byte rows.
+// LDS: M strips (32 KiB, shared) + 16 tile rows x 64 columns per wave and pass, pitch 66 doubles.
+// ---------------------------------------------------------------------------------------
+constexpr int EPI_PITCH = 66;                       // doubles per LDS row (16-byte aligned rows)
+constexpr int EPI_M_BYTES = NB * NB * 8;            // M strips, shared by the workgroup's tiles
+constexpr int EPI_WAVE_BYTES = 16 * EPI_PITCH * 8;  // 16 tile rows x 64 columns per wave and pass
+constexpr int EPI_LDS_BYTES = EPI_M_BYTES + 4 * EPI_WAVE_BYTES;   // 66,560 B
+
+// all 256 threads: M (strip order, 32 KiB) global -> LDS; callers put a barrier after it
+__device__ __forceinline__ void stage_mstrips(double *lds_m, const double *mstrips, int tid) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = tid + 256 * i;   // f64x2 units
+        reinterpret_cast<f64x2 *>(lds_m)[idx] = reinterpret_cast<const f64x2 *>(mstrips)[idx];
+    }
+}
+
+__device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], double *Lr,
+                                                    const double *lds_m, long ld, int kmax,
+                                                    int lane, double *buf, int dbg = 0) {
+    const int n16 = lane & 15, isub = lane >> 4;
+    const int jj0 = 4 * (n16 >> 2) + isub;          // row of S' inside a 16-tile
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                // 16 tile rows per pass
+        double c4[4][4];   // C' = K' - S' for this 16-row group of the tile
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + ((n16 + 4 * r) & 15);
+                const double kv = (dbg & 8) ? 1.0 : Lr[(long)i * ld + kmax + 16 * jt + jj0];
+                c4[jt][r] = kv - acc4[jt][it][r];
+            }
+        if (dbg & 16) {   // timing ablation: no M C' product
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) buf[n16 * EPI_PITCH + 16 * jt + isub] = c4[jt][0] + c4[jt][1] + c4[jt][2] + c4[jt][3];
+        } else
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {            // output rows 16 ct ..: C' tiles jt <= ct
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) {
+                const int cb4 = 4 * ct + cq;
+                double R[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int jt = 0; jt <= ct; ++jt) {
+                    const double a = lds_m[(cb4 * 4 + jt) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) R[r] = mfma4(a, c4[jt][r], R[r]);
+                }
+                // lane group b of R[r] holds the partial sum for tile rows 4 ((b + r) & 3) ..:
+                // rotating R[r] by r lane groups lines all four partial sums up on the lanes
+                // i = n16, where they are added (fixed order: deterministic)
+                double x = R[0];
+                x += dpp_f64<ROW_ROR4, 0xF>(R[1], R[1]);
+                x += dpp_f64<ROW_ROR8, 0xF>(R[2], R[2]);
+                x += dpp_f64<ROW_ROR12, 0xF>(R[3], R[3]);
+                buf[n16 * EPI_PITCH + 4 * cb4 + isub] = x;   // X'[c = 4 cb4 + isub][i = 16 it + n16]
+            }
+        }
+        // rows 16 it .. 16 it + 15 of the tile: 32 lanes x 16 B per 512-byte row
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int idx = w * 64 + lane, row = idx >> 5, cp = idx & 31;
+            const f64x2 v = *reinterpret_cast<const f64x2 *>(buf + row * EPI_PITCH + 2 * cp);
+            if (!(dbg & 32) || (v.x == 1.2345e-300))
+                *reinterpret_cast<f64x2 *>(Lr + (long)(16 * it + row) * ld + kmax + 2 * cp) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// tile[i][c0 + jj] -= S'[jj][i], straight from the 4x4x4 register layout
+__device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, int c0,
+                                                       const double (*acc4)[4][4], int lane) {
+    const int n16 = lane & 15, isub = lane >> 4;
+    const int jj0 = 4 * (n16 >> 2) + isub;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double *e = rows + (long)(16 * it + ((n16 + 4 * r) & 15)) * ld + c0 + 16 * jt + jj0;
+                *e -= acc4[jt][it][r];
+            }
+}
+
 struct ColStep {
     int j;        // block column being finished
     int k0;       // first k not yet accumulated into column j
@@ -763,24 +895,24 @@ struct ColStep {
 template <bool FAT>
 __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                           ColStep st) {
+    __shared__ __attribute__((aligned(16))) char epi[EPI_LDS_BYTES];
     const int wg = blockIdx.x;
     const int xcd = wg & 7, idx = wg >> 3;   // blocks b and b+8 share an XCD (speed only)
     const int item = (idx / st.groups) * 8 + xcd;
     const int grp = idx % st.groups;
-    if (item >= Bc) return;
+    if (item >= Bc) return;                  // whole workgroup, before any barrier
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = grp * 4 + wave;
     const int tile = FAT ? (slot >> 1) : slot;   // row tile
     const int col = FAT ? (slot & 1) : 0;        // 0: column j, 1: column j+1 (partial)
-    if (tile >= st.ntiles) return;
+    const bool valid = tile < st.ntiles;
 
     const int j = st.j;
     const long ld = g.ld;
     double *Lit = p.L + (long)item * g.item_stride;
     const int kmax = j * NB;
     const int r16 = lane & 15, q = lane >> 4;
-    const int naux_tiles = g.naux_pad / NB;
 
     double acc4[4][4][4];  // [jt][it][r]: block-diagonal r of S' tile (jt, it), see mfma16_as_4
 #pragma unroll
@@ -790,28 +922,22 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
 
-    if (FAT && st.ahead && tile == st.nmain + naux_tiles) {
-        // diag-ahead: K_(j+2,j+2) -= L_(j+2),[0,kmax) L_(j+2),[0,kmax)'  (one wave of the pair)
-        if (col) return;
-        double *Ld = Lit + (long)(j + 2) * NB * ld;
-        const double *pd = Ld + (long)r16 * ld + 2 * q;
-        gemm_rows<4>(acc4, pd, pd, ld, 0, kmax);
-        subtract_in_place(Ld, ld, (j + 2) * NB, acc4, r16, q);
-        return;
-    }
-
-    const long rowbase = (tile < st.nmain) ? (long)(j + 1 + tile) * NB
-                                           : (long)g.n0 + (long)(tile - st.nmain) * NB;
+    const int vt = valid ? tile : 0;
+    const long rowbase = (vt < st.nmain) ? (long)(j + 1 + vt) * NB
+                                         : (long)g.n0 + (long)(vt - st.nmain) * NB;
     double *Lr = Lit + rowbase * ld;
     const double *Lj = Lit + (long)(j + col) * NB * ld;   // A operand: rows of block j (+1)
     const double *pa = Lj + (long)r16 * ld + 2 * q;
     const double *pb = Lr + (long)r16 * ld + 2 * q;        // B operand: rows of this tile
-    gemm_rows<4>(acc4, pa, pb, ld, st.k0, kmax);
+    if (valid) gemm_rows<4>(acc4, pa, pb, ld, st.k0, kmax);
+    stage_mstrips(reinterpret_cast<double *>(epi), p.dinv + (long)item * (NB * NB), tid);
+    __syncthreads();
+    if (!valid) return;
     if (FAT && col) {
-        subtract_in_place(Lr, ld, (j + 1) * NB, acc4, r16, q);   // column j+1, partial sum
+        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane);   // column j+1, partial sum
     } else {
-        const double *dinv = p.dinv + (long)item * (NB / TB) * (TB * TB);
-        solve_and_store(acc4, Lr, Lj, dinv, ld, kmax, r16, q);
+        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
+                            reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES));
     }
 }
 
@@ -944,6 +1070,11 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
             if (!(st.dbg & 2)) __syncthreads();
         }
     }
+    // the staging buffers are free (every wave passed the k-loop's last barrier): M strips go to
+    // LDS for both tiles of the workgroup
+    static_assert(EPI_LDS_BYTES <= 2 * STAGE, "epilogue LDS must fit the stage buffers");
+    stage_mstrips(reinterpret_cast<double *>(smem), p.dinv + (long)item * (NB * NB), tid);
+    __syncthreads();
     if (!valid) return;
     if (st.dbg & 4) {   // timing ablation: keep the accumulators alive, skip the epilogue
         double sum = 0.0;
@@ -958,12 +1089,12 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     }
 
     double *Lr = Lit + tile_row0(tile) * ld;
-    const double *Lj = Lit + (long)(j + col) * NB * ld;
     if (col) {
-        subtract_in_place(Lr, ld, (j + 1) * NB, acc4, r16, q);
+        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane);
     } else {
-        const double *dinv = p.dinv + (long)item * (NB / TB) * (TB * TB);
-        solve_and_store(acc4, Lr, Lj, dinv, ld, kmax, r16, q);
+        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
+                            reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES),
+                            st.dbg);
     }
 }
 
