@@ -274,3 +274,83 @@ def test_gradient_random_trees_and_child_reordering(ctx, n, lattice):
         assert i0 == 0 and nerr(lm[b], rlm) < tol(TOL_LOGML, cond)
         assert grads[b].shape == rg.shape
         assert nerr(grads[b], rg) < tol(1e-7, cond), (b, grads[b], rg)
+
+
+# ----------------------------------------------------------------------------------------------
+# edge cases of the boundary (empty / minimal / maximal inputs)
+# ----------------------------------------------------------------------------------------------
+def test_minimal_shapes(ctx):
+    prog = gp.to_program(gp.Plus(gp.Linear(0.2, 0.1, 0.5), gp.Periodic(0.9, 0.3, 0.7))) + (0.05,)
+    # one item, one point
+    lm, info = ctx.logml_batch([prog], [0.3], [0.7])
+    ref, _ = oracle_c.logml(prog, [0.3], [0.7])
+    assert info[0] == 0 and nerr(lm[0], ref) < 1e-12
+    # no appended points (d = 0) and no forecast points (m = 0) through the nowcast entry point
+    t = np.arange(70) / 69
+    y = np.cos(5 * t)
+    out = ctx.nowcast_batch([prog], t, y, [], np.zeros((1, 0)), [])
+    assert out["mu"] is None and out["sigma"] is None
+    assert nerr(out["logml_base"][0], oracle_c.logml(prog, t, y)[0]) < 1e-10
+    assert nerr(out["logml_full"][0, 0], out["logml_base"][0]) < 1e-14
+    # exactly one block, no tail (n = 64), single scenario
+    t = np.arange(64) / 63
+    y = np.sin(4 * t)
+    out = ctx.nowcast_batch([prog], t, y, [1.02], [[0.1]], [1.05])
+    lb, lf, mu, sg, _ = oracle_np.nowcast(prog, t, y, [1.02], [[0.1]], [1.05])
+    assert nerr(out["logml_full"][0], lf) < 1e-10 and nerr(out["mu"][0], mu) < 1e-8
+
+
+def test_maximum_aux_rows_and_largest_program(ctx):
+    rng = np.random.Generator(np.random.PCG64(8))
+    # 63 tail points + 60 appended + 68 forecast + 1 data row = 192 = NGP_MAX_AUX
+    n, d, m = 127, 60, 68
+    t_all = np.arange(n + d + m) / (n - 1)
+    y = rng.standard_normal(n)
+    y_add = rng.standard_normal((2, d))
+    # a 63-node tree: 32 leaves joined by 31 Plus nodes (NGP_MAX_OPS = 64)
+    leaves = [gp.Periodic(0.8 + 0.01 * i, 0.1 + 0.02 * i, 0.05) if i % 2 else
+              gp.GammaExponential(0.2 + 0.01 * i, 1.2, 0.05) for i in range(32)]
+    while len(leaves) > 1:
+        leaves = [gp.Plus(a, b) for a, b in zip(leaves[::2], leaves[1::2])]
+    prog = gp.to_program(leaves[0]) + (0.05,)
+    assert len(prog[0]) == 63
+    out = ctx.nowcast_batch([prog], t_all[:n], y, t_all[n:n + d], y_add, t_all[n + d:])
+    lb, lf, mu, sg, info = oracle_np.nowcast(prog, t_all[:n], y, t_all[n:n + d], y_add,
+                                             t_all[n + d:])
+    cond = np.linalg.cond(oracle_np.cov(prog, t_all[:n + d], t_all[:n + d], True))
+    assert out["info"][0] == 0 and info == 0
+    assert nerr(out["logml_full"][0], lf) < tol(TOL_LOGML, cond)
+    assert nerr(out["mu"][0], mu) < tol(TOL_PRED, cond)
+    assert nerr(out["sigma"][0], sg) < tol(TOL_PRED, cond)
+    # one more aux row is refused, not truncated
+    t_more = np.arange(n + d + m + 1) / (n - 1)
+    with pytest.raises(_lib.NgpError):
+        ctx.nowcast_batch([prog], t_more[:n], y, t_more[n:n + d + 1],
+                          rng.standard_normal((1, d + 1)), t_more[n + d + 1:])
+
+
+def test_limits_are_refused(ctx):
+    # 65 ops > NGP_MAX_OPS
+    big = ([2] * 33 + [6] * 32, [0.1] * 99, 0.1)
+    with pytest.raises(_lib.NgpError):
+        ctx.logml_batch([big], [0.0, 0.5, 1.0], [0.0, 1.0, 2.0])
+    # empty batch / empty series
+    with pytest.raises(_lib.NgpError):
+        ctx.logml_batch([], [0.0, 1.0], [0.0, 1.0])
+    prog = gp.to_program(gp.Linear(0.0, 1.0, 1.0)) + (0.1,)
+    with pytest.raises(_lib.NgpError):
+        ctx.logml_batch([prog], [], [])
+
+
+def test_long_history_8192(ctx):
+    """BASELINE.json's n = 8192 configuration, fp64 (the fp32-factor variant is not built):
+    one oracle item + size-independent properties."""
+    w = make_workload("C5", P=3, D=2)
+    out = ctx.nowcast_batch(w.programs, w.t, w.y, w.t_add, w.y_add, w.t_new)
+    assert not out["info"].any() and np.isfinite(out["logml_full"]).all()
+    lm_n, _ = ctx.logml_batch(w.programs, w.t, w.y)
+    assert nerr(out["logml_base"], lm_n) < 1e-11
+    tt = np.concatenate([w.t, w.t_add])
+    lf, i0 = oracle_np.logml(w.programs[0], tt, np.concatenate([w.y, w.y_add[0]]))
+    # (no SVD of an 8193 x 8193 matrix in the test: flat 1e-9 instead of the cond-aware bound)
+    assert i0 == 0 and nerr(out["logml_full"][0, 0], lf) < 1e-9
