@@ -65,6 +65,37 @@ def cpu_baseline(w, progs, Y, sample_items, threads):
     return len(idx) / dt, len(idx), dt, res, idx
 
 
+def fit_forecast_wallclock(w, device):
+    """End-to-end wall-clock of the two reference call sites through the host mirror and the HIP
+    engine: make_and_fit_model (SMC over 10 data-annealing steps, structure MH + HMC rejuvenation)
+    then forecast_with_nowcasts over all scenarios (reference src/make_and_fit_model.jl:98-113,
+    src/forecasting.jl:230-280).  Sampler settings are deliberately light (the step that matters
+    for throughput is the batched hot path timed above); they are printed with the result."""
+    import datetime as dt
+
+    from nowcastautogp_amd import autogp
+    from nowcastautogp_amd import nowcast as nc
+    n, D, d, m = w.n, w.y_add.shape[0], w.t_add.size, w.t_new.size
+    P = len(w.programs)
+    d0 = dt.date(2000, 1, 2)
+    dates = [d0 + dt.timedelta(weeks=i) for i in range(n + d + m)]
+    data = nc.create_transformed_data(dates[:n], w.y, transformation=float)
+    eng = autogp.HipEngine(device)
+    settings = dict(n_particles=P, smc_data_proportion=0.1, n_mcmc=2, n_hmc=2,
+                    hmc_config={"n_leapfrog": 5, "eps": 0.01})
+    t0 = time.perf_counter()
+    model = nc.make_and_fit_model(data, engine=eng, seed=7, **settings)
+    t_fit = time.perf_counter() - t0
+    scen = nc.create_nowcast_data([row for row in w.y_add], dates[n:n + d])
+    t0 = time.perf_counter()
+    fc = nc.forecast_with_nowcasts(model, scen, dates[n + d:], 20)
+    t_fc = time.perf_counter() - t0
+    ok = bool(np.isfinite(fc).all()) and fc.shape == (m, D * 20)
+    return {"fit_s": t_fit, "forecast_with_nowcasts_s": t_fc, "n": n, "particles": P,
+            "scenarios": D, "draws_per_scenario": 20, "settings": {k: v for k, v in settings.items()},
+            "finite_and_shaped": ok}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +106,8 @@ def main():
     ap.add_argument("--scenarios", type=int, default=None)
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fit", action="store_true",
+                    help="skip the end-to-end make_and_fit_model + forecast_with_nowcasts timing")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items in the CPU sample (0: auto)")
     args = ap.parse_args()
 
@@ -156,6 +189,10 @@ def main():
     shared_ms = (time.perf_counter() - ts) / 3 * 1e3
     job2.close()
 
+    fit_res = None
+    if rank == 0 and not args.no_fit:
+        fit_res = fit_forecast_wallclock(w, local_rank)
+
     if rank == 0:
         col = prof.get("chol_col", dict(ms=0.0, flops=0.0, launches=0, bytes=0.0))
         total_ms = sum(v["ms"] for v in prof.values())
@@ -206,6 +243,8 @@ def main():
                 "reference_equivalent_evals_per_s": 2 * B / (shared_ms * 1e-3),
             },
         }
+        if fit_res is not None:
+            res["fit_forecast"] = fit_res
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             sample = args.cpu_sample or max(2 * cores, 8)
