@@ -648,21 +648,21 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
 //
 //   C_rj -= L_r,[k0,k1) L_j,[k0,k1)'    then    L_rj = C_rj L_jj^-T
 //
-// One 64-row tile per wave, 4 tiles per workgroup.  The transposed tile C' is accumulated so the
-// solve can consume the accumulators as MFMA B operands in place.
+// One 64 x 64 tile per wave; the transposed tile S' = L_j L_r' is accumulated with the 4x4x4 MFMA
+// form (A operand = rows of block j, B operand = the tile's rows) and consumed by the epilogue in
+// that register layout.
 //
 // HBM traffic of a left-looking factorisation is one pass over all previous columns of every row
 // tile per block column; at the 4x4x4 MFMA rate a 64-wide block column needs ~4.7 TB/s of that
-// (measured: the kernel turned bandwidth-bound).  So block columns are processed in pairs with
-// register-level reuse of the streamed rows:
-//   FAT  step (j even):  accumulate column j over k < 64 j AND pre-accumulate column j+1 over the
-//                        same k from the same B-operand registers (64 x 128 per wave, 256
-//                        accumulator VGPRs, one wave per SIMD); column j is finished (solve +
-//                        store), column j+1's partial sum is subtracted from K in place.
-//   THIN step (j odd):   only k in [64 (j-1), 64 j) is left.
-//   FULL step:           single column over all k (last column of an odd count).
-// The fat launch also pre-accumulates the diagonal tile (j+2, j+2) over k < 64 j ("diag-ahead"
-// tile), so chol_diag never runs a long k-loop on one workgroup.
+// (measured: the kernel turned bandwidth-bound).  So block columns are processed in pairs:
+//   FAT  step (j even):  chol_col_glds_kernel — column j is accumulated over k < 64 j and finished
+//                        (solve + store) by one wave, while its sibling wave pre-accumulates
+//                        column j+1 over the same k from the same LDS-staged rows and subtracts
+//                        the partial sum from K in place;
+//   THIN step (j odd):   chol_col_kernel — only k in [64 (j-1), 64 j) is left;
+//   FULL step:           chol_col_kernel — single column over all k (last column of an odd count).
+// Beside the fat launch, diag_ahead_kernel pre-accumulates the diagonal tile (j+2, j+2) over
+// k < 64 j on a side stream, so chol_diag never runs a long k-loop on one workgroup.
 // ---------------------------------------------------------------------------------------
 // 8 k-values of NF 16-row fragments: lane (r16, q) holds rows 16u + r16, k = kc + 2q, 2q + 1
 template <int NF>
@@ -712,72 +712,6 @@ __device__ __forceinline__ void gemm_rows(double (&acc)[NA][4][4], const double 
         }
         mfma_frag8(acc, a1, b1);
     }
-}
-
-// tile[i][c0 + jj] -= S'[jj][i] for a 64 x 64 tile held as four-by-four block-diagonal accumulators
-__device__ __forceinline__ void subtract_in_place(double *rows, long ld, int c0,
-                                                  const double (*acc4)[4][4], int r16, int q) {
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const f64x4 d = to_d16(acc4[jt][it]);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                double *e = rows + (long)(16 * it + r16) * ld + c0 + 16 * jt + q + 4 * s;
-                *e -= d[s];
-            }
-        }
-}
-
-// Finish column j of one tile: C' = K' - S', X' = L_jj^-1 C' by 16-row block substitution
-//   X'_ct = Dinv_ct (C'_ct - sum_{jt<ct} L_jj[ct][jt] X'_jt)
-// on the 16x16x4 C/D layout (a D tile is directly the B operand of a product that sums over its
-// row index), then store L_rj.  The K tile is pulled in one 16-column slab per ct.
-__device__ __forceinline__ void solve_and_store(const double (*acc4)[4][4], double *Lr,
-                                                const double *Lj, const double *dinv, long ld,
-                                                int kmax, int r16, int q) {
-    f64x4 acc[4][4];  // acc[jt][it]: S'[jj = 16jt + q + 4s][i = 16it + r16]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = to_d16(acc4[a][b]);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        f64x4 tmp[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                tmp[it][s] = Lr[(long)(16 * it + r16) * ld + kmax + 16 * ct + q + 4 * s] -
-                             acc[ct][it][s];
-#pragma unroll
-        for (int jt = 0; jt < ct; ++jt) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const double a = -Lj[(long)(16 * ct + r16) * ld + kmax + 16 * jt + q + 4 * s];
-#pragma unroll
-                for (int it = 0; it < 4; ++it) tmp[it] = mfma64(a, acc[jt][it][s], tmp[it]);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) acc[ct][it] = (f64x4){0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double a = dinv[ct * (TB * TB) + r16 * TB + q + 4 * s];
-#pragma unroll
-            for (int it = 0; it < 4; ++it) acc[ct][it] = mfma64(a, tmp[it][s], acc[ct][it]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // store L_rj: X'[c = 16ct + q + 4s][i = 16it + r16] -> L_r[i][kmax + c]
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                Lr[(long)(16 * it + r16) * ld + kmax + 16 * ct + q + 4 * s] = acc[ct][it][s];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -879,20 +813,15 @@ struct ColStep {
     int j;        // block column being finished
     int k0;       // first k not yet accumulated into column j
     int nmain;    // main row tiles below the diagonal (r = j+1 ...)
-    int ntiles;   // nmain + aux tiles (+ 1 diag-ahead tile when fat && ahead)
+    int ntiles;   // nmain + aux tiles
     int groups;   // workgroups per item
-    int ahead;    // fat only: 1 if the tile (j+2, j+2) is pre-accumulated by an extra tile
-    int dbg;      // timing ablations (results wrong when != 0): 1 no restaging, 2 no barriers,
-                  // 4 no epilogue; set from the NGP_ABLATE environment variable, never by the API
+    int ahead;    // unused (the diag-ahead tile has its own kernel)
+    int dbg;      // timing ablations of the fat kernel (results wrong when != 0): 1 no restaging,
+                  // 2 no barriers, 4 no epilogue, 8 no K-tile reads, 16 no M C' product, 32 no row
+                  // stores; from the NGP_ABLATE environment variable only, never through the API
 };
 
-// FAT launches pair the waves of a workgroup: waves 2t and 2t+1 take the SAME 64 tile rows (the
-// second fetch of every streamed line hits L1/L2, so HBM sees the rows once per two block
-// columns); the even wave finishes column j, the odd wave pre-accumulates column j+1 and
-// subtracts it from K in place.  128 accumulator VGPRs per wave, two waves per SIMD.
-// (A 64 x 128 tile in one wave needs 256 accumulators; hipcc then splits them across the
-// AGPR/VGPR halves and moves them every iteration — measured 2x slower.)
-template <bool FAT>
+// THIN and FULL steps: direct operand loads (short k-loops), one row tile per wave.
 __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                           ColStep st) {
     __shared__ __attribute__((aligned(16))) char epi[EPI_LDS_BYTES];
@@ -903,9 +832,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     if (item >= Bc) return;                  // whole workgroup, before any barrier
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slot = grp * 4 + wave;
-    const int tile = FAT ? (slot >> 1) : slot;   // row tile
-    const int col = FAT ? (slot & 1) : 0;        // 0: column j, 1: column j+1 (partial)
+    const int tile = grp * 4 + wave;             // row tile
     const bool valid = tile < st.ntiles;
 
     const int j = st.j;
@@ -926,19 +853,15 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     const long rowbase = (vt < st.nmain) ? (long)(j + 1 + vt) * NB
                                          : (long)g.n0 + (long)(vt - st.nmain) * NB;
     double *Lr = Lit + rowbase * ld;
-    const double *Lj = Lit + (long)(j + col) * NB * ld;   // A operand: rows of block j (+1)
+    const double *Lj = Lit + (long)j * NB * ld;            // A operand: rows of block j
     const double *pa = Lj + (long)r16 * ld + 2 * q;
     const double *pb = Lr + (long)r16 * ld + 2 * q;        // B operand: rows of this tile
     if (valid) gemm_rows<4>(acc4, pa, pb, ld, st.k0, kmax);
     stage_mstrips(reinterpret_cast<double *>(epi), p.dinv + (long)item * (NB * NB), tid);
     __syncthreads();
     if (!valid) return;
-    if (FAT && col) {
-        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane);   // column j+1, partial sum
-    } else {
-        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
-                            reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES));
-    }
+    solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
+                        reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES));
 }
 
 constexpr int LDS_KC = 16;   // k-depth of one staged chunk
@@ -953,7 +876,9 @@ constexpr int LDS_KC = 16;   // k-depth of one staged chunk
 //     address (row (n' + 4r) mod 16) instead of DPP moves: the k-loop is ds_read_b64 + MFMA only;
 //   * the operand rows go HBM -> LDS directly (buffer_load_dwordx4 ... lds: no VGPR round trip, no
 //     ds_write).  A register-staged predecessor (padded 136-B rows, ds_write2_b64) measured 11 %
-//     slower on the same box.  An LDS-DMA instruction writes 1 KiB contiguously (8 rows x 128 B here), so rows cannot
+//     slower on the same box.  (A 64 x 128 tile in ONE wave would give register-level reuse, but
+//     needs 256 accumulators; hipcc then splits them across the AGPR/VGPR halves and moves them
+//     every iteration — measured 2x slower — hence two sibling waves x 64 x 64.)  An LDS-DMA instruction writes 1 KiB contiguously (8 rows x 128 B here), so rows cannot
 // be padded; bank conflicts are removed by an XOR swizzle applied on the SOURCE address
 // (slot p of row r holds the 16-byte piece p ^ ((r>>1)&7)) and again on the read address
 // (guide rule: linear destination + swizzled source + the same swizzle on the read).  The
@@ -1114,7 +1039,7 @@ __global__ __launch_bounds__(64, 2) void diag_ahead_kernel(JobGeom g, ChunkPtrs 
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
     const double *pd = Ld + (long)r16 * ld + 2 * q;
     gemm_rows<4>(acc4, pd, pd, ld, 0, j * NB);
-    subtract_in_place(Ld, ld, (j + 2) * NB, acc4, r16, q);
+    subtract_in_place_perm(Ld, ld, (j + 2) * NB, acc4, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1580,7 +1505,7 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
         (void)ahead;
     } else {
         st.groups = (st.ntiles + 3) / 4;
-        hipLaunchKernelGGL(chol_col_kernel<false>, dim3(st.groups * bpad), dim3(256), 0, s, g, p,
+        hipLaunchKernelGGL(chol_col_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p,
                            Bc, st);
     }
 }

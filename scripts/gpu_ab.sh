@@ -3,5 +3,5 @@
 for r in 1 2; do
 for v in a b; do
   lib=$GRAFT_REPO_ROOT/nowcastautogp_amd/libngp_$v.so; [ $v = b ] && lib=$GRAFT_REPO_ROOT/nowcastautogp_amd/libngp.so
-  echo "== $v round $r"; NGP_LIB=$lib python bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" | grep -o '"ms_per_step.\{22\}\|kernels_ms_per_step.\{200\}'
+  echo "== $v round $r"; NGP_LIB=$lib python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fit "$@" | grep -o '"ms_per_step.\{22\}\|kernels_ms_per_step.\{200\}'
 done; done
