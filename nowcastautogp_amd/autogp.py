@@ -350,7 +350,17 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
     def potential(zs):
         progs, dths = [], []
         for z, kd, op in zip(zs, kinds, ops):
-            th, dth = gp.transform(z, kd, prior)
+            th, dth = gp.transform(np.nan_to_num(z, nan=0.0, posinf=50.0, neginf=-50.0), kd, prior)
+            # degenerate parameters (a diverged trajectory) would only produce a non-PD matrix
+            # and a rejection; keep them inside what the kernels accept
+            th = np.clip(th, -1e6, 1e6)
+            for i_, k_ in enumerate(kd):
+                if k_ in ("wildcard", "period"):
+                    th[i_] = max(th[i_], 1e-12)
+                elif k_ == "gamma":
+                    th[i_] = min(max(th[i_], 1e-9), 2.0 - 1e-9)
+                elif k_ == "unit":
+                    th[i_] = min(max(th[i_], 1e-9), 1.0 - 1e-9)
             progs.append((op, th[:-1], float(th[-1])))
             dths.append(dth)
         lm, grads, info = model._eng().logml_grad(progs, t, y)

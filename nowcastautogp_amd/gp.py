@@ -213,6 +213,19 @@ def param_kinds(ops: Sequence[int]) -> List[str]:
     return out
 
 
+def _sigmoid(x: float) -> float:
+    if x >= 0:
+        return 1.0 / (1.0 + math.exp(-min(x, 700.0)))
+    e = math.exp(max(x, -700.0))
+    return e / (1.0 + e)
+
+
+def _exp_clamped(x: float) -> float:
+    # a divergent HMC trajectory may push a latent far out; keep the map finite so the move is
+    # simply rejected instead of raising
+    return math.exp(min(max(x, -300.0), 300.0))
+
+
 def transform(z: np.ndarray, kinds: Sequence[str], prior) -> Tuple[np.ndarray, np.ndarray]:
     """latents z -> parameters theta and d theta / d z (elementwise)."""
     z = np.asarray(z, dtype=np.float64)
@@ -222,15 +235,15 @@ def transform(z: np.ndarray, kinds: Sequence[str], prior) -> Tuple[np.ndarray, n
         if kd == "real":
             th[i], dth[i] = z[i], 1.0
         elif kd == "unit":
-            s = 1.0 / (1.0 + math.exp(-z[i]))
+            s = _sigmoid(z[i])
             th[i], dth[i] = s, s * (1 - s)
         elif kd == "gamma":
             pr = prior["gamma"]
-            s = 1.0 / (1.0 + math.exp(-(pr["mu"] + pr["sigma"] * z[i])))
+            s = _sigmoid(pr["mu"] + pr["sigma"] * z[i])
             th[i], dth[i] = 2.0 * s, 2.0 * s * (1 - s) * pr["sigma"]
         else:
             pr = prior["period"] if kd == "period" else prior["wildcard"]
-            v = math.exp(pr["mu"] + pr["sigma"] * z[i])
+            v = _exp_clamped(pr["mu"] + pr["sigma"] * z[i])
             th[i], dth[i] = v, v * pr["sigma"]
     return th, dth
 

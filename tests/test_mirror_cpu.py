@@ -117,3 +117,17 @@ def test_product_default_engine_fails_loudly_without_gpu():
     data = nc.create_transformed_data(mc.days(0, 10), np.arange(10.0) + 1, transformation=float)
     with pytest.raises(RuntimeError):
         nc.make_and_fit_model(data, n_particles=1, n_mcmc=1, n_hmc=1)
+
+
+def test_divergent_hmc_trajectory_is_rejected_not_raised(eng):
+    """a wildly too large step size sends latents to +-inf: the move must be rejected cleanly and the
+    particle state must stay finite and self-consistent"""
+    model = mc.fitted(eng, seed=13, n_particles=2)
+    before = [p.program() for p in model.particles]
+    autogp.mcmc_parameters(model, 2, hmc_config={"eps": 50.0, "n_leapfrog": 6})
+    t, y = model._obs()
+    fresh, info = eng.logml(model.programs(), t, y)
+    assert not info.any() and np.isfinite(fresh).all()
+    assert np.allclose(model._logml, fresh, rtol=1e-9)
+    for p, b in zip(model.particles, before):
+        assert np.isfinite(p.program()[1]).all() and p.noise > 0
