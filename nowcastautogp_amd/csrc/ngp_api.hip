@@ -907,11 +907,11 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     const size_t l_bytes = (size_t)g.item_stride * 8;
     const size_t tab_bytes = g.lattice ? 8 * (size_t)g.maxstat * g.R : 0;
     const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
-    const size_t item_bytes = l_bytes + tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 +
+    const size_t item_bytes = l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 +
                               8 * (size_t)g.n0 + 8 * (size_t)ntri * GP;
     int Bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, c->mem_cap / item_bytes));
     void *d_prog, *d_t, *d_y, *d_q = nullptr, *d_logdet, *d_info, *d_L, *d_dinv, *d_tab = nullptr,
-         *d_sig = nullptr, *d_kinv, *d_alpha, *d_quad, *d_part, *d_grad, *d_logml;
+         *d_sig = nullptr, *d_dtab = nullptr, *d_kinv, *d_alpha, *d_quad, *d_part, *d_grad, *d_logml;
     ngp_status st;
     if ((st = dalloc(&d_prog, sizeof(DevProgram) * (size_t)B)) ||
         (st = dalloc(&d_t, 8 * (size_t)g.n0)) || (st = dalloc(&d_y, 8 * h_y.size())) ||
@@ -920,7 +920,8 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         (st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
         (st = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
         (g.lattice && ((st = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
-                       (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)))) ||
+                       (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)) ||
+                       (st = dalloc(&d_dtab, 3 * tab_bytes * (size_t)Bc)))) ||
         (st = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||
         (st = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) || (st = dalloc(&d_quad, 8 * (size_t)Bc)) ||
         (st = dalloc(&d_part, 8 * (size_t)Bc * ntri * GP)) ||
@@ -952,6 +953,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         p.tab = (double *)d_tab;
         p.sig = (double *)d_sig;
         p.qpts = (const int32_t *)d_q;
+        p.dtab = (double *)d_dtab;
         if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
         tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + (double)g.naux * g.n0),
                [&] { launch_fill(g, p, bc, sp, s); });
@@ -962,10 +964,10 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
                              (double *)d_quad, bc, s);
         });
         tm.run(5, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
-            launch_grad_contract(g, p.progs, (const double *)d_t, (const double *)d_kinv,
-                                 (const double *)d_alpha, (const double *)d_quad, p.logdet,
-                                 (double *)d_part, (double *)d_grad + (int64_t)b0 * GP,
-                                 (double *)d_logml + b0, bc, sp, s);
+            launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
+                                 (const double *)d_quad, (double *)d_part,
+                                 (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc,
+                                 sp, s);
         });
     }
     std::vector<double> h_grad((size_t)B * GP), h_lm((size_t)B);

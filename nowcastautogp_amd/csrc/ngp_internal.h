@@ -74,6 +74,8 @@ struct ChunkPtrs {
     double       *tab;    // [Bc][maxstat][R]   stationary-leaf values by lattice distance
     double       *sig;    // [Bc][maxcp][npts]  ChangePoint sigmoids by point
     const int32_t *qpts;  // [npts] lattice coordinate of every point (t0 then taux)
+    double       *dtab;   // [Bc][maxstat][3][R] gradient jobs on a lattice: per stationary leaf the
+                          // unscaled factor e and the two parameter-derivative factors (else null)
 };
 
 struct EpiPtrs {
@@ -102,10 +104,9 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
                       int Bc, hipStream_t s);
-void launch_grad_contract(const JobGeom &g, const DevProgram *progs, const double *t0,
-                          const double *Kinv, const double *alpha, const double *quad,
-                          const double *logdet, double *partials, double *grad, double *logml,
-                          int Bc, const DevSpec &sp, hipStream_t s);
+void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
+                          const double *alpha, const double *quad, double *partials, double *grad,
+                          double *logml, int Bc, const DevSpec &sp, hipStream_t s);
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s);
 void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipStream_t s);
 void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2,

@@ -287,29 +287,48 @@ __global__ __launch_bounds__(256) void tables_kernel(JobGeom g, ChunkPtrs p, Dev
     __syncthreads();
     double *tab = p.tab + (long)item * g.maxstat * g.R;
     double *sig = p.sig + (long)item * g.maxcp * g.npts;
+    // gradient jobs: dt = [slot][3][R]: e (the leaf value without its amplitude) and the two
+    // factors its lengthscale-type derivatives need, so the O(n^2) contraction is lookups + FMAs
+    double *dt = p.dtab ? p.dtab + (long)item * g.maxstat * 3 * g.R : nullptr;
     int pi = 0;
     for (int i = 0; i < P.n_ops; ++i) {
         const int op = __builtin_amdgcn_readfirstlane((int)P.ops[i]);
         const int slot = __builtin_amdgcn_readfirstlane((int)P.slot[i]);
+        double *d0 = dt ? dt + (long)slot * 3 * g.R : nullptr;
         if (op == NGP_OP_SQEXP) {
             const double l = P.params[pi], a = P.params[pi + 1];
             const double den = sp.se_form ? l : l * l;
             for (int k = threadIdx.x; k < g.R; k += 256) {
                 const double d = k * g.h;
-                tab[(long)slot * g.R + k] = a * exp(-0.5 * d * d / den);
+                const double e = exp(-0.5 * d * d / den);
+                tab[(long)slot * g.R + k] = a * e;
+                if (d0) d0[k] = e;
             }
             pi += 2;
         } else if (op == NGP_OP_GAMMAEXP) {
             const double l = P.params[pi], gam = P.params[pi + 1], a = P.params[pi + 2];
-            for (int k = threadIdx.x; k < g.R; k += 256)
-                tab[(long)slot * g.R + k] = a * exp(-pow(k * g.h / l, gam));
+            for (int k = threadIdx.x; k < g.R; k += 256) {
+                const double rr = k * g.h / l, u = pow(rr, gam), e = exp(-u);
+                tab[(long)slot * g.R + k] = a * e;
+                if (d0) {
+                    d0[k] = e;
+                    d0[g.R + k] = e * u;                                  // -> d / d lengthscale
+                    d0[2 * g.R + k] = (k > 0) ? e * u * log(rr) : 0.0;    // -> d / d gamma
+                }
+            }
             pi += 3;
         } else if (op == NGP_OP_PERIODIC) {
             const double l = P.params[pi], per = P.params[pi + 1], a = P.params[pi + 2];
             const double c = sp.periodic_form ? 2.0 / l : 2.0 / (l * l);
             for (int k = threadIdx.x; k < g.R; k += 256) {
-                const double sn = sin(M_PI * (k * g.h) / per);
-                tab[(long)slot * g.R + k] = a * exp(-c * sn * sn);
+                const double d = k * g.h, ang = M_PI * d / per;
+                const double sn = sin(ang), e = exp(-c * sn * sn);
+                tab[(long)slot * g.R + k] = a * e;
+                if (d0) {
+                    d0[k] = e;
+                    d0[g.R + k] = e * sn * sn;                 // -> d / d lengthscale
+                    d0[2 * g.R + k] = e * sn * cos(ang) * d;   // -> d / d period
+                }
             }
             pi += 3;
         } else if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
@@ -833,7 +852,17 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = grp * 4 + wave;             // row tile
-    const bool valid = tile < st.ntiles;
+    bool valid = tile < st.ntiles;
+    // gradient jobs: aux rows are [I ; y'], so W = X L^-T is block upper triangular — identity
+    // tile a is zero left of block column a (skip it while a > j) and its k-loop starts at 64 a
+    int kbeg = st.k0;
+    if (g.aux_identity && valid && tile >= st.nmain) {
+        const int a = tile - st.nmain;
+        if (a < g.nb0) {
+            if (a > st.j) valid = false;
+            else if (a * NB > kbeg) kbeg = a * NB;
+        }
+    }
 
     const int j = st.j;
     const long ld = g.ld;
@@ -856,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     const double *Lj = Lit + (long)j * NB * ld;            // A operand: rows of block j
     const double *pa = Lj + (long)r16 * ld + 2 * q;
     const double *pb = Lr + (long)r16 * ld + 2 * q;        // B operand: rows of this tile
-    if (valid) gemm_rows<4>(acc4, pa, pb, ld, st.k0, kmax);
+    if (valid) gemm_rows<4>(acc4, pa, pb, ld, kbeg, kmax);
     stage_mstrips(reinterpret_cast<double *>(epi), p.dinv + (long)item * (NB * NB), tid);
     __syncthreads();
     if (!valid) return;
@@ -907,12 +936,31 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     const int ltile = wave >> 1, col = wave & 1;
     const int tile0 = grp * 2;
     const int tile = tile0 + ltile;
-    const bool valid = tile < st.ntiles;
+    bool valid = tile < st.ntiles;
 
     const int j = st.j;
     const long ld = g.ld;
     double *Lit = p.L + (long)item * g.item_stride;
     const int kmax = j * NB;
+    // gradient jobs (aux rows [I ; y']): identity tile a is zero left of block column a.  The two
+    // tiles of a workgroup share the staged k-range, so it starts at the smaller of their starts;
+    // a workgroup whose tiles are all still zero leaves before the first barrier.
+    int kbeg = st.k0;
+    if (g.aux_identity && tile0 >= st.nmain) {
+        // workgroup-uniform: first k of each of the two tiles (kmax + 1: nothing to do)
+        int kfirst = kmax + 1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int a = tile0 + u - st.nmain;
+            if (tile0 + u >= st.ntiles) continue;
+            const int ks = (a >= g.nb0) ? st.k0 : (a > j) ? kmax + 1 : max(st.k0, a * NB);
+            kfirst = min(kfirst, ks);
+        }
+        if (kfirst > kmax) return;
+        kbeg = kfirst;
+        const int a = tile - st.nmain;
+        if (valid && a < g.nb0 && a > j) valid = false;
+    }
     const int r16 = lane & 15, q = lane >> 4;
     auto tile_row0 = [&](int t) -> long {
         if (t >= st.ntiles) t = st.ntiles - 1;
@@ -967,13 +1015,13 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
 
-    const int nchunks = (kmax - st.k0) / LDS_KC;
+    const int nchunks = (kmax - kbeg) / LDS_KC;
     if (nchunks > 0) {
-        stage(0, st.k0);
+        stage(0, kbeg);
         __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
         for (int c = 0; c < nchunks; ++c) {
             const int cur = c & 1;
-            if (c + 1 < nchunks && !(st.dbg & 1)) stage(cur ^ 1, st.k0 + (c + 1) * LDS_KC);
+            if (c + 1 < nchunks && !(st.dbg & 1)) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
             const char *buf = smem + cur * STAGE;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -1378,6 +1426,145 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(JobGeom g, const Dev
             red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// The same contraction on lattice times: every transcendental of the tree comes from the per-item
+// tables (tab / dtab by integer distance, sig by point), so the n^2/2 element loop is lookups and
+// FMAs only.  ChangePoint: sigma = (1 + tanh u)/2 gives d sigma / du = 2 sigma (1 - sigma).
+__global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, ChunkPtrs p,
+                                                                    const double *Kinv,
+                                                                    const double *alpha,
+                                                                    double *partials, int ntri,
+                                                                    DevSpec sp) {
+    __shared__ DevProgram P;
+    __shared__ double red[4][NGP_MAX_PARAMS + 1];
+    const int item = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    load_program(&P, p.progs + item);
+    __syncthreads();
+    int r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+    while (r * (r + 1) / 2 > tile) --r;
+    const int c = tile - r * (r + 1) / 2;
+    const int tx = tid & 63, ty = tid >> 6;
+    const int col = c * NB + tx;
+    const int np = P.n_params, nops = P.n_ops;
+    const int R = g.R, npts = g.npts;
+    const double *tab = p.tab + (long)item * g.maxstat * R;
+    const double *dt = p.dtab + (long)item * g.maxstat * 3 * R;
+    const double *sig = p.sig + (long)item * g.maxcp * npts;
+    double gacc[NGP_MAX_PARAMS + 1];
+    for (int i = 0; i <= np; ++i) gacc[i] = 0.0;
+    const double *Ki = Kinv + (long)item * g.n0 * g.n0;
+    const double *al = alpha + (long)item * g.n0;
+    if (col < g.n_real) {
+        const double t2 = p.t0[col], ac = al[col];
+        const int q2 = p.qpts[col];
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = r * NB + ty * 16 + rr;
+            if (row >= g.n_real || col > row) continue;
+            double w = al[row] * ac - Ki[(long)row * g.n0 + col];
+            if (row == col) w *= 0.5;
+            const double t1 = p.t0[row];
+            const double d = fabs(t1 - t2);
+            const int dq = abs(p.qpts[row] - q2);
+            // ---- forward sweep: value of every node
+            double val[NGP_MAX_OPS];
+            for (int i = 0; i < nops; ++i) {
+                const int op = P.ops[i], po = P.poff[i];
+                double v;
+                if (op == NGP_OP_CONSTANT) v = P.params[po];
+                else if (op == NGP_OP_LINEAR)
+                    v = P.params[po + 1] + P.params[po + 2] * (t1 - P.params[po]) * (t2 - P.params[po]);
+                else if (op < NGP_OP_PLUS) v = tab[(long)P.slot[i] * R + dq];
+                else {
+                    const double x = val[P.first[i]], y = val[i - 1];   // first-evaluated, second
+                    if (op == NGP_OP_PLUS) v = x + y;
+                    else if (op == NGP_OP_TIMES) v = x * y;
+                    else {
+                        const double kl = (op == NGP_OP_CHANGEPOINT) ? x : y;
+                        const double kr = (op == NGP_OP_CHANGEPOINT) ? y : x;
+                        const double g1 = sig[(long)P.slot[i] * npts + row];
+                        const double g2 = sig[(long)P.slot[i] * npts + col];
+                        v = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+                    }
+                }
+                val[i] = v;
+            }
+            // ---- reverse sweep: adjoint stack mirrors the evaluation stack
+            double s0 = w, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+            for (int i = nops - 1; i >= 0; --i) {
+                const int op = P.ops[i], po = P.poff[i];
+                const double a = s0;
+                s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;   // pop
+                if (op == NGP_OP_CONSTANT) {
+                    gacc[po] += a;
+                } else if (op == NGP_OP_LINEAR) {
+                    const double cc = P.params[po], a1 = t1 - cc, a2 = t2 - cc;
+                    gacc[po] += a * P.params[po + 2] * (-a1 - a2);
+                    gacc[po + 1] += a;
+                    gacc[po + 2] += a * a1 * a2;
+                } else if (op < NGP_OP_PLUS) {
+                    const double *d0 = dt + (long)P.slot[i] * 3 * R + dq;
+                    const double e = d0[0];
+                    if (op == NGP_OP_SQEXP) {
+                        const double l = P.params[po], am = P.params[po + 1];
+                        gacc[po] += a * am * e * d * d * (sp.se_form ? 0.5 / (l * l) : 1.0 / (l * l * l));
+                        gacc[po + 1] += a * e;
+                    } else if (op == NGP_OP_GAMMAEXP) {
+                        const double l = P.params[po], gm = P.params[po + 1], am = P.params[po + 2];
+                        gacc[po] += a * am * gm * d0[R] / l;
+                        gacc[po + 1] -= a * am * d0[2 * R];
+                        gacc[po + 2] += a * e;
+                    } else {
+                        const double l = P.params[po], per = P.params[po + 1], am = P.params[po + 2];
+                        const double cq = sp.periodic_form ? 2.0 / l : 2.0 / (l * l);
+                        gacc[po] += a * am * d0[R] * (sp.periodic_form ? 2.0 / (l * l) : 4.0 / (l * l * l));
+                        gacc[po + 1] += a * am * cq * 2.0 * M_PI * d0[2 * R] / (per * per);
+                        gacc[po + 2] += a * e;
+                    }
+                } else {
+                    const double x = val[P.first[i]], y = val[i - 1];
+                    double ax, ay;   // adjoints of the first-evaluated and the second operand
+                    if (op == NGP_OP_PLUS) {
+                        ax = a; ay = a;
+                    } else if (op == NGP_OP_TIMES) {
+                        ax = a * y; ay = a * x;
+                    } else {
+                        const bool nat = (op == NGP_OP_CHANGEPOINT);
+                        const double kl = nat ? x : y, kr = nat ? y : x;
+                        const double loc = P.params[po], sc = P.params[po + 1];
+                        const double sgn = sp.cp_form ? 1.0 : -1.0;   // u = sgn (t - loc) / sc
+                        const double u1 = sgn * (t1 - loc) / sc, u2 = sgn * (t2 - loc) / sc;
+                        const double g1 = sig[(long)P.slot[i] * npts + row];
+                        const double g2 = sig[(long)P.slot[i] * npts + col];
+                        const double q1 = 2.0 * g1 * (1.0 - g1), q2_ = 2.0 * g2 * (1.0 - g2);
+                        const double d1l = q1 * (-sgn / sc), d2l = q2_ * (-sgn / sc);
+                        const double d1s = q1 * (-u1 / sc), d2s = q2_ * (-u2 / sc);
+                        gacc[po] += a * (d1l * kl * g2 + g1 * kl * d2l - d1l * kr * (1.0 - g2) -
+                                         (1.0 - g1) * kr * d2l);
+                        gacc[po + 1] += a * (d1s * kl * g2 + g1 * kl * d2s - d1s * kr * (1.0 - g2) -
+                                             (1.0 - g1) * kr * d2s);
+                        const double al_ = a * g1 * g2, ar_ = a * (1.0 - g1) * (1.0 - g2);
+                        ax = nat ? al_ : ar_;
+                        ay = nat ? ar_ : al_;
+                    }
+                    s7 = s5; s6 = s4; s5 = s3; s4 = s2; s3 = s1; s2 = s0; s1 = ax; s0 = ay;
+                }
+            }
+            if (row == col) gacc[np] += w;   // d K / d noise = I (w already carries the 1/2)
+        }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int pidx = 0; pidx <= np; ++pidx) {
+        double v = gacc[pidx];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][pidx] = v;
+    }
+    __syncthreads();
+    if (tid <= np)
+        partials[((long)item * ntri + tile) * (NGP_MAX_PARAMS + 1) + tid] =
+            red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 __global__ __launch_bounds__(128) void grad_reduce_kernel(JobGeom g, const DevProgram *progs,
                                                           const double *partials, const double *quad,
                                                           const double *logdet, double *grad,
@@ -1523,15 +1710,18 @@ void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *a
                        alpha, quad);
 }
 
-void launch_grad_contract(const JobGeom &g, const DevProgram *progs, const double *t0,
-                          const double *Kinv, const double *alpha, const double *quad,
-                          const double *logdet, double *partials, double *grad, double *logml,
-                          int Bc, const DevSpec &sp, hipStream_t s) {
+void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
+                          const double *alpha, const double *quad, double *partials, double *grad,
+                          double *logml, int Bc, const DevSpec &sp, hipStream_t s) {
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
-    hipLaunchKernelGGL(grad_contract_kernel, dim3(ntri, Bc), dim3(256), 0, s, g, progs, t0, Kinv,
-                       alpha, partials, ntri, sp);
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3(Bc), dim3(128), 0, s, g, progs, partials, quad,
-                       logdet, grad, logml, ntri);
+    if (g.lattice && p.dtab)
+        hipLaunchKernelGGL(grad_contract_lattice_kernel, dim3(ntri, Bc), dim3(256), 0, s, g, p,
+                           Kinv, alpha, partials, ntri, sp);
+    else
+        hipLaunchKernelGGL(grad_contract_kernel, dim3(ntri, Bc), dim3(256), 0, s, g, p.progs, p.t0,
+                           Kinv, alpha, partials, ntri, sp);
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(Bc), dim3(128), 0, s, g, p.progs, partials, quad,
+                       p.logdet, grad, logml, ntri);
 }
 
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s) {

@@ -254,7 +254,8 @@ def test_gradient_matches_oracle_on_golden(ctx, golden):
     ctx.set_spec(NgpSpec(0, 0, 0, 0, 1e-5))
 
 
-@pytest.mark.parametrize("n,lattice", [(70, True), (200, True), (150, False)])
+@pytest.mark.parametrize("n,lattice", [(70, True), (200, True), (150, False), (330, True),
+                                       (400, False), (577, True)])
 def test_gradient_random_trees_and_child_reordering(ctx, n, lattice):
     rng = np.random.Generator(np.random.PCG64(31 + n))
     progs = make_ensemble(rng, 7, depth_cap=5)
