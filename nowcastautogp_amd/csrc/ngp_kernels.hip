@@ -463,11 +463,34 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
 // ---------------------------------------------------------------------------------------
 // chol_diag: factor the 64x64 diagonal block of block column j
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, int j, int k0) {
-    __shared__ double At[NB][NB + 1];
-    __shared__ double Lt[NB][NB + 1];
+// d = sqrt(a) and r = 1/d for a pivot, on the serial critical path of the factorisation: one
+// v_rsq_f64 seed, two Newton steps on the reciprocal root, one correction each for d and r
+// (a dozen dependent FMAs instead of the ~40 of sqrt() followed by a division; both results
+// within 1 ulp).  a <= 0 or NaN gives non-finite values; the caller flags the pivot.
+__device__ __forceinline__ void sqrt_and_rcp(double a, double &d, double &r) {
+    double y = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    d = a * y;
+    d = fma(fma(-d, d, a), 0.5 * y, d);
+    r = fma(fma(-d, y, 1.0), y, y);
+}
+
+// Lower-triangular tiles live in LDS packed by rows (38 KB per workgroup in total, so four
+// workgroups share a CU: the kernel is a chain of short dependent phases and gains from occupancy).
+__device__ __forceinline__ int tri(int r, int c) { return ((r * (r + 1)) >> 1) + c; }   // r >= c
+constexpr int TRI = NB * (NB + 1) / 2;
+
+__global__ __launch_bounds__(256, 4) void chol_diag_kernel(JobGeom g, ChunkPtrs p, int j, int k0) {
+    __shared__ double Mt[TRI];        // C_jj while it is staged, then M = L_jj^-1
+    __shared__ double Lt[TRI];        // L_jj
+    __shared__ double pan[NB][4];     // the 64x4 panel of the current round
+    __shared__ double dblk[16];       // 4x4 factor of the current diagonal block, row-major
+    __shared__ double dinvd[4];       // reciprocals of its diagonal
+    __shared__ double rdg[NB];        // 1 / diag(L_jj)
     __shared__ double logs[NB];
-    __shared__ double red_scratch[TB * (TB + 1)];
+    __shared__ double Ts[TB][TB + 1];
     __shared__ int bad;
     const int item = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -479,7 +502,6 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
     const int r16 = lane & 15, q = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
 
-    for (int e = tid; e < NB * (NB + 1); e += 256) (&Lt[0][0])[e] = 0.0;
     if (tid == 0) bad = 0;
 
     // ---- C_jj = K_jj - L_j L_j'   (each wave one 32x32 quadrant; the strictly upper one is
@@ -494,6 +516,17 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
                 for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
         const double *pa = Lj + (long)(32 * wr + r16) * ld + 2 * q;
         const double *pb = Lj + (long)(32 * wc + r16) * ld + 2 * q;
+        // the K tile itself, in the D layout of the product (loaded first: its latency hides
+        // under the k-loop): register s of kt[mt][nt] is K[32wr+16mt+q+4s][32wc+16nt+r16]
+        double kt[2][2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    kt[mt][nt][s] = Lj[(long)(32 * wr + 16 * mt + q + 4 * s) * ld + kmax +
+                                       32 * wc + 16 * nt + r16];
         for (int kc = k0; kc < kmax; kc += 16) {
             double a[2][4], b[2][4];
 #pragma unroll
@@ -527,99 +560,144 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int M = 32 * wr + 16 * mt + q + 4 * s, N = 32 * wc + 16 * nt + r16;
-                    At[M][N] = Lj[(long)M * ld + kmax + N] - acc[mt][nt][s];
+                    if (M >= N) Mt[tri(M, N)] = kt[mt][nt][s] - acc[mt][nt][s];
                 }
     }
     __syncthreads();
 
     // ---- right-looking Cholesky of the 64x64 tile, register-blocked: thread (bi, bj) owns the 4x4
-    //      block rows 4bi.., cols 4bj..; per pivot only the (unscaled) pivot column travels through
-    //      LDS (double-buffered, one barrier per pivot), every thread rescales what it needs and
-    //      updates its 16 elements in registers.  Same operation order as the textbook loop:
-    //      a_ij -= (a_ik / sqrt(a_kk)) (a_jk / sqrt(a_kk)).
+    //      block rows 4bi.., cols 4bj...  Four pivots are retired per round (16 rounds, two barriers
+    //      each): the diagonal thread factors its 4x4 block in registers, the threads of block
+    //      column kb solve their block against it and post the 64x4 panel through LDS, the blocks
+    //      to the right apply the rank-4 update in registers.  Per element the operations and
+    //      their order are those of the textbook loop  a_ij -= l_ik l_jk,  k ascending — only the
+    //      synchronisation is coarser (one pivot per barrier measured 38 us of this kernel's 63).
+    const int bi = tid >> 4, bj = tid & 15;
     {
-        double(*colbuf)[NB] = reinterpret_cast<double(*)[NB]>(&Lt[0][0]);  // Lt is free until the end
-        const int bi = tid >> 4, bj = tid & 15;
         double a[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a[r][c] = At[4 * bi + r][4 * bj + c];
-        __syncthreads();   // everyone has its block: Lt may now be reused as the column buffer
+            for (int c = 0; c < 4; ++c) {
+                const int R = 4 * bi + r, C = 4 * bj + c;
+                a[r][c] = (R >= C) ? Mt[tri(R, C)] : 0.0;
+            }
         for (int kb = 0; kb < NB / 4; ++kb) {
+            if (bi == kb && bj == kb) {
+                double dks[4];
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) {
-                const int k = 4 * kb + kc;
-                double *cb = colbuf[k & 1];
-                if (bj == kb) {
+                for (int kc = 0; kc < 4; ++kc) {
+                    const double akk = a[kc][kc];
+                    double dk, inv;
+                    sqrt_and_rcp(akk, dk, inv);
+                    if (!(akk > 0.0) && bad == 0) bad = 4 * kb + kc + 1;
+                    dks[kc] = dk;
+                    dinvd[kc] = inv;
+                    rdg[4 * kb + kc] = inv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) cb[4 * bi + r] = a[r][kc];
+                    for (int r = 0; r < 4; ++r)
+                        if (r > kc) a[r][kc] *= inv;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c > kc) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (r >= c) a[r][c] -= a[r][kc] * a[c][kc];
+                        }
                 }
-                __syncthreads();
-                const double akk = cb[k];
-                const double dk = sqrt(akk);
-                const double inv = 1.0 / dk;
-                if (tid == 0) {
-                    if (!(akk > 0.0) && bad == 0) bad = k + 1;
-                    logs[k] = log(dk);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (r == c) a[r][c] = dks[r];
+                        if (c > r) a[r][c] = 0.0;
+                        dblk[4 * r + c] = a[r][c];
+                    }
+            }
+            __syncthreads();
+            if (bj == kb && bi > kb) {
+                // x[r][c] = (a[r][c] - sum_{p<c} x[r][p] L[c][p]) / L[c][c], p ascending
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double inv = dinvd[c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double v = a[r][c];
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp)
+                            if (pp < c) v -= a[r][pp] * dblk[4 * c + pp];
+                        a[r][c] = v * inv;
+                    }
                 }
-                double li[4], lj[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) li[r] = cb[4 * bi + r] * inv;
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) lj[c] = cb[4 * bj + c] * inv;
-                if (bj > kb) {
+                    for (int c = 0; c < 4; ++c) pan[4 * bi + r][c] = a[r][c];
+            }
+            __syncthreads();
+            if (bj > kb && bi >= bj) {
+                double li[4][4], lj[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        li[r][pp] = pan[4 * bi + r][pp];
+                        lj[r][pp] = pan[4 * bj + r][pp];
+                    }
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) a[r][c] -= li[r] * lj[c];
-                } else if (bj == kb) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (c > kc) a[r][c] -= li[r] * lj[c];
-                        const int row = 4 * bi + r;
-                        a[r][kc] = row > k ? li[r] : (row == k ? dk : 0.0);   // column k of L
-                    }
-                }
+                        for (int c = 0; c < 4; ++c) a[r][c] -= li[r][pp] * lj[c][pp];
             }
         }
-        __syncthreads();   // column buffer no longer read: Lt becomes the output tile
-        for (int e = tid; e < NB * (NB + 1); e += 256) (&Lt[0][0])[e] = 0.0;
-        __syncthreads();
-        if (bj <= bi) {
+        // L_jj: to LDS for the inverse, and straight from the registers back to the factor
+        // storage (strict upper part zero)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+            const int R = 4 * bi + r;
+            f64x2 lo, hi;
+            lo.x = (R >= 4 * bj) ? a[r][0] : 0.0;
+            lo.y = (R >= 4 * bj + 1) ? a[r][1] : 0.0;
+            hi.x = (R >= 4 * bj + 2) ? a[r][2] : 0.0;
+            hi.y = (R >= 4 * bj + 3) ? a[r][3] : 0.0;
+            double *dst = Lj + (long)R * ld + kmax + 4 * bj;
+            *reinterpret_cast<f64x2 *>(dst) = lo;
+            *reinterpret_cast<f64x2 *>(dst + 2) = hi;
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (4 * bi + r >= 4 * bj + c) Lt[4 * bi + r][4 * bj + c] = a[r][c];
+            for (int c = 0; c < 4; ++c)
+                if (R >= 4 * bj + c) Lt[tri(R, 4 * bj + c)] = a[r][c];
         }
     }
     __syncthreads();
+    if (tid < NB) logs[tid] = log(Lt[tri(tid, tid)]);
 
     // ---- M = L_jj^-1 (64 x 64, lower): the four 16x16 diagonal-block inverses by forward
     //      substitution (column c of block b per thread), then the six off-diagonal tiles by block
     //      recursion  M[ct][jt] = -M[ct][ct] (sum_{k=jt}^{ct-1} L[ct][k] M[k][jt]),  one tile at a
-    //      time over 256 threads.  At is free now and holds M.
-    for (int e = tid; e < NB * (NB + 1); e += 256) (&At[0][0])[e] = 0.0;
-    __syncthreads();
+    //      time over 256 threads.  Mt is free now (C_jj went to registers before the factorisation).
     if (tid < NB) {
         const int b = tid >> 4, c = tid & 15;
         double x[TB];
 #pragma unroll
         for (int i = 0; i < TB; ++i) {
             double sum = (i == c) ? 1.0 : 0.0;
+            int off = tri(TB * b + i, TB * b);   // one address per row, pp by offset
+            // tie the row's address to the previous result: otherwise hipcc issues all 120 LDS
+            // reads up front and spills them (measured: 178 spilled VGPRs at 4 waves/SIMD)
+            if (i > 0) asm volatile("" : "+v"(off) : "v"(x[i - 1]));
+            const double *lrow = &Lt[off];
 #pragma unroll
-            for (int pp = 0; pp < i; ++pp) sum -= Lt[TB * b + i][TB * b + pp] * x[pp];
-            x[i] = sum / Lt[TB * b + i][TB * b + i];
+            for (int pp = 0; pp < i; ++pp) sum -= lrow[pp] * x[pp];
+            x[i] = sum * rdg[TB * b + i];
         }
 #pragma unroll
-        for (int i = 0; i < TB; ++i) At[TB * b + i][TB * b + c] = x[i];
+        for (int i = 0; i < TB; ++i)
+            if (i >= c) Mt[tri(TB * b + i, TB * b + c)] = x[i];
     }
     __syncthreads();
     {
-        double(*Ts)[TB + 1] = reinterpret_cast<double(*)[TB + 1]>(&red_scratch[0]);
         const int ra = tid >> 4, cb = tid & 15;
         for (int dist = 1; dist < NB / TB; ++dist)
             for (int ct = dist; ct < NB / TB; ++ct) {
@@ -627,14 +705,20 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
                 double t = 0.0;
                 for (int kt = jt; kt < ct; ++kt)
 #pragma unroll
-                    for (int pp = 0; pp < TB; ++pp)
-                        t += Lt[TB * ct + ra][TB * kt + pp] * At[TB * kt + pp][TB * jt + cb];
+                    for (int pp = 0; pp < TB; ++pp) {
+                        // M[16kt+pp][16jt+cb]: inside the diagonal block (kt == jt) zero above it
+                        const double mv = Mt[tri(TB * kt + pp, TB * jt + cb)];
+                        t += Lt[tri(TB * ct + ra, TB * kt + pp)] * ((kt > jt || pp >= cb) ? mv : 0.0);
+                    }
                 Ts[ra][cb] = t;
                 __syncthreads();
                 double mv = 0.0;
 #pragma unroll
-                for (int pp = 0; pp < TB; ++pp) mv -= At[TB * ct + ra][TB * ct + pp] * Ts[pp][cb];
-                At[TB * ct + ra][TB * jt + cb] = mv;
+                for (int pp = 0; pp < TB; ++pp) {
+                    const double md = Mt[tri(TB * ct + ra, TB * ct + pp)];
+                    mv -= ((pp <= ra) ? md : 0.0) * Ts[pp][cb];
+                }
+                Mt[tri(TB * ct + ra, TB * jt + cb)] = mv;
                 __syncthreads();
             }
     }
@@ -646,13 +730,9 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(JobGeom g, ChunkPtrs p, 
         for (int e = tid; e < NB * NB; e += 256) {
             const int strip = e >> 6, l = e & 63;
             const int cb4 = strip >> 2, jt = strip & 3;
-            dv[e] = At[4 * cb4 + (l & 3)][16 * jt + 4 * ((l >> 2) & 3) + (l >> 4)];
+            const int R = 4 * cb4 + (l & 3), C = 16 * jt + 4 * ((l >> 2) & 3) + (l >> 4);
+            dv[e] = (R >= C) ? Mt[tri(R, C)] : 0.0;
         }
-    }
-    // ---- write L_jj back (strict upper part zero)
-    for (int e = tid; e < NB * NB; e += 256) {
-        const int M = e >> 6, N = e & 63;
-        Lj[(long)M * ld + kmax + N] = Lt[M][N];
     }
     if (tid == 0) {
         double s = 0.0;
