@@ -198,6 +198,32 @@ ngp_status ngp_job_fetch(ngp_job *job, double *logml_base, double *logml_full,
                          double *mu, double *sigma, int32_t *info);
 void       ngp_job_destroy(ngp_job *job);
 
+/* ---- cached factor ------------------------------
+ * A fitted model is queried many times with the same particles and the same
+ * training data: forecast() on several date grids, forecast_with_nowcasts()
+ * after it (src/forecasting.jl:159, 248).  ngp_factor_create factorises the P
+ * training covariances ONCE and keeps L (and the block inverses the solves
+ * use) resident on the device; a query then only fills its aux rows (appended
+ * points, forecast points, y) and sweeps them through L: O(n^2 (d + m)) per
+ * particle instead of n^3 / 3.  Queries return exactly what
+ * ngp_nowcast_batch returns for the same arguments (d = 0: plain predict).
+ * The handle owns device memory of about 8 n (n + 192) bytes per particle;
+ * it copies the kernels and the data it was created with.
+ *   create : y is [P][n] with row stride ldy (0: one y shared by all)
+ *   logml  : log p(y | particle) and the factorisation status of create
+ *   nowcast: d + m <= NGP_MAX_AUX - (n mod 64) - 1                            */
+typedef struct ngp_factor ngp_factor;
+ngp_status ngp_factor_create(ngp_ctx *ctx, int32_t P, const ngp_kernel *kernels,
+                             int32_t n, const double *t, const double *y, int64_t ldy,
+                             ngp_factor **out);
+ngp_status ngp_factor_logml(const ngp_factor *f, double *logml, int32_t *info);
+ngp_status ngp_factor_nowcast(ngp_factor *f, int32_t d, const double *t_add,
+                              int32_t D, const double *y_add,
+                              int32_t m, const double *t_new, int32_t noise_on_new,
+                              double *logml_base, double *logml_full,
+                              double *mu, double *sigma, int32_t *info);
+void       ngp_factor_destroy(ngp_factor *f);
+
 /* ---- measurement hooks -----------------------------------------------------
  * HIP-event timing of the kernels a job launches, on the stream they are
  * launched on.  Classes: 0 = chol_col (trailing-update GEMM + fused solve, the

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -26,7 +27,8 @@ SYMBOLS = (
     "ngp_strerror", "ngp_version", "ngp_kernel_check", "ngp_cov_batch", "ngp_logml_batch",
     "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
-    "ngp_job_destroy", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
+    "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
+    "ngp_factor_destroy", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
     "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
 )
 
@@ -86,6 +88,11 @@ def load():
         "ngp_job_run": (i32, [vp]),
         "ngp_job_fetch": (i32, [vp, f64p, f64p, f64p, f64p, i32p]),
         "ngp_job_destroy": (None, [vp]),
+        "ngp_factor_create": (i32, [vp, i32, KP, i32, f64p, f64p, i64, C.POINTER(vp)]),
+        "ngp_factor_logml": (i32, [vp, f64p, i32p]),
+        "ngp_factor_nowcast": (i32, [vp, i32, f64p, i32, f64p, i32, f64p, i32, f64p, f64p, f64p,
+                                     f64p, i32p]),
+        "ngp_factor_destroy": (None, [vp]),
         "ngp_profile_enable": (i32, [vp, i32]),
         "ngp_profile_reset": (i32, [vp]),
         "ngp_profile_get": (i32, [vp, C.POINTER(NgpProfile)]),
@@ -138,6 +145,7 @@ class Job:
     def __init__(self, ctx: "Context", handle, P: int, D: int, m: int, keep):
         self.ctx, self._h, self.P, self.D, self.m = ctx, handle, P, D, m
         self._keep = keep
+        ctx._children.add(self)
 
     def run(self):
         _chk(load().ngp_job_run(self._h), "ngp_job_run")
@@ -154,9 +162,57 @@ class Job:
         return dict(logml_base=lb, logml_full=lf, mu=mu, sigma=sg, info=info)
 
     def close(self):
-        if self._h is not None:
+        # the handle points into its context: a context closed first has already closed us
+        if self._h is not None and self.ctx._h is not None:
             load().ngp_job_destroy(self._h)
-            self._h = None
+        self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Factor:
+    """Training covariances of P kernels factorised once and kept on the device (``ngp_factor``):
+    every query sweeps only its appended / forecast rows through the resident L."""
+
+    def __init__(self, ctx: "Context", handle, P: int):
+        self.ctx, self._h, self.P = ctx, handle, P
+        ctx._children.add(self)
+
+    def logml(self):
+        lm, info = np.empty(self.P), np.zeros(self.P, dtype=np.int32)
+        _chk(load().ngp_factor_logml(self._h, dptr(lm), iptr(info)), "ngp_factor_logml")
+        return lm, info
+
+    def nowcast(self, t_add, y_add, t_new, noise_on_new=True):
+        """Same result dict as ``Context.nowcast_batch`` (``t_add`` empty: plain predict)."""
+        t_add, t_new = as_f64(t_add), as_f64(t_new)
+        d, m = t_add.size, t_new.size
+        y_add = as_f64(y_add).reshape(-1, d) if d else np.zeros((1, 0))
+        D = y_add.shape[0]
+        P = self.P
+        lb, lf = np.empty(P), np.empty((P, D))
+        mu = np.empty((P, D, m)) if m else None
+        sg = np.empty((P, m, m)) if m else None
+        info = np.zeros(P, dtype=np.int32)
+        _chk(load().ngp_factor_nowcast(self._h, d, dptr(t_add) if d else None, D,
+                                       dptr(y_add) if d else None, m,
+                                       dptr(t_new) if m else None, int(noise_on_new), dptr(lb),
+                                       dptr(lf), _nullable(mu), _nullable(sg), iptr(info)),
+             "ngp_factor_nowcast")
+        return dict(logml_base=lb, logml_full=lf, mu=mu, sigma=sg, info=info)
+
+    def predict(self, t_new, noise_on_new=True):
+        r = self.nowcast(np.zeros(0), np.zeros((1, 0)), t_new, noise_on_new)
+        return r["mu"][:, 0, :], r["sigma"], r["logml_full"][:, 0], r["info"]
+
+    def close(self):
+        if self._h is not None and self.ctx._h is not None:
+            load().ngp_factor_destroy(self._h)
+        self._h = None
 
     def __del__(self):  # pragma: no cover
         try:
@@ -176,11 +232,14 @@ class Context:
             raise NgpError(int(st), "ngp_ctx_create (the GP hot path has no CPU fallback)")
         self._h = h
         self.device = device
+        self._children = weakref.WeakSet()
         if spec is not None:
             self.set_spec(spec)
 
     def close(self):
         if getattr(self, "_h", None) is not None:
+            for child in list(getattr(self, "_children", ())):   # jobs / factors hold ctx pointers
+                child.close()
             load().ngp_ctx_destroy(self._h)
             self._h = None
 
@@ -257,6 +316,16 @@ class Context:
                                       dptr(lf), _nullable(mu), _nullable(sg), iptr(info)),
              "ngp_nowcast_batch")
         return dict(logml_base=lb, logml_full=lf, mu=mu, sigma=sg, info=info)
+
+    def factor(self, programs, t, y) -> Factor:
+        """Factorise once, query many times (``ngp_factor_create``)."""
+        ka = KernelArray(programs)
+        t = as_f64(t)
+        y, ldy = self._ymat(y, ka.n, t.size)
+        h = C.c_void_p()
+        _chk(load().ngp_factor_create(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy,
+                                      C.byref(h)), "ngp_factor_create")
+        return Factor(self, h, ka.n)
 
     def logml_grad_batch(self, programs, t, y):
         ka = KernelArray(programs)

@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import copy
 import datetime as _dt
+import hashlib
 import math
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -63,6 +64,26 @@ class HipEngine:
 
     def nowcast(self, programs, t, y, t_add, y_add, t_new, noise_on_new=True):
         return self.ctx.nowcast_batch(programs, t, y, t_add, y_add, t_new, noise_on_new)
+
+    def factor(self, programs, t, y):
+        """Factorise once, keep L on the device (``ngp_factor``): repeated forecasts of a fitted
+        model only pay for their appended / forecast rows."""
+        return self.ctx.factor(programs, t, y)
+
+
+class _FactorCache:
+    """(digest, device handle); deep copies of a model start without one."""
+
+    def __init__(self, key, factor):
+        self.key, self.factor = key, factor
+
+    def close(self):
+        if self.factor is not None:
+            self.factor.close()
+            self.factor = None
+
+    def __deepcopy__(self, memo):
+        return _FactorCache(None, None)
 
 
 _default_engine = None
@@ -198,6 +219,37 @@ class GPModel:
 
     def programs(self):
         return [p.program() for p in self.particles]
+
+    # -- cached factorisation of the current ensemble on the current data ------------------------
+    def _factor(self):
+        """The engine's resident factor for (particles, observed data), or None if the engine has
+        none (or the training set is longer than one handle can be queried on).  The handle is
+        keyed on a digest of exactly what it was built from, so any move that changes a particle
+        or the data simply misses; it is never part of ``Dict(model)``."""
+        make = getattr(self._eng(), "factor", None)
+        if make is None:
+            return None
+        t, y = self._obs()
+        progs = self.programs()
+        h = hashlib.blake2b(digest_size=16)
+        for ops, params, noise in progs:
+            h.update(np.asarray(ops, dtype=np.int32).tobytes())
+            h.update(np.asarray(params, dtype=np.float64).tobytes())
+            h.update(np.float64(noise).tobytes())
+        h.update(t.tobytes())
+        h.update(y.tobytes())
+        key = h.digest()
+        cache = self.__dict__.get("_fcache")
+        if cache is None or cache.key != key:
+            if cache is not None:
+                cache.close()
+            try:
+                fac = make(progs, t, y)
+            except (RuntimeError, MemoryError):   # e.g. the ensemble does not fit: one-shot path
+                fac = None
+            cache = _FactorCache(key, fac)
+            self.__dict__["_fcache"] = cache
+        return cache.factor
 
     # -- Dict(model) / GPModel(dict)  (reference src/forecasting.jl:241,246) ----------------------
     def to_dict(self) -> dict:
@@ -507,7 +559,11 @@ class MixtureMVN:
 def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
     t, y = model._obs()
     t_new = model.ds_transform.apply(to_days(list(ds)))
-    mu, sigma, _, info = model._eng().predict(model.programs(), t, y, t_new, noise_on_new)
+    fac = model._factor()
+    if fac is not None:
+        mu, sigma, _, info = fac.predict(t_new, noise_on_new)
+    else:
+        mu, sigma, _, info = model._eng().predict(model.programs(), t, y, t_new, noise_on_new)
     bad = np.flatnonzero(info)
     if bad.size:
         raise PosDefException(int(info[bad[0]]), int(bad[0]))

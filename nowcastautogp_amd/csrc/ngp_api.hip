@@ -404,7 +404,10 @@ inline Lane lane_of(ngp_ctx *c, int i) {
                   : Lane{c->stream2, c->side2, c->ev_fork2, c->ev_join2};
 }
 
-void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p, int bc, EventTimer &tm) {
+// dinv_step != 0: block column jj writes / reads its M at p.dinv + jj * dinv_step (cached factor:
+// every M_j is kept); 0: one buffer reused by every step.
+void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p0, int bc, EventTimer &tm,
+                  size_t dinv_step = 0) {
     hipStream_t s = ln.main;
     const double nrows_aux = (double)g.naux;
     bool ahead_pending = false;
@@ -419,6 +422,8 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p, int bc, 
         const int k0_diag = thin ? (jj - 1) * NB : (jj >= 2 ? (jj - 2) * NB : 0);
         const double k = (double)jj * NB;
         const double kd = k - k0_diag;
+        ChunkPtrs p = p0;
+        p.dinv = p0.dinv + (size_t)jj * dinv_step;
         // the diag-ahead tile (jj, jj) was launched on the side stream at step jj-2, beside
         // diag(jj-1) / col(jj-1); chol_diag(jj) is its only consumer
         if (ahead_pending && (jj % 2 == 0)) {
@@ -441,7 +446,7 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p, int bc, 
         if (ahead && jj > 0) {
             (void)hipEventRecord(ln.fork, s);
             (void)hipStreamWaitEvent(ln.side, ln.fork, 0);
-            launch_diag_ahead(g, p, bc, jj, ln.side);
+            launch_diag_ahead(g, p0, bc, jj, ln.side);
             (void)hipEventRecord(ln.join, ln.side);
             ahead_pending = true;
         }
@@ -798,6 +803,226 @@ extern "C" ngp_status ngp_nowcast_batch(ngp_ctx *c, int32_t P, const ngp_kernel 
                                       &job);
     if (st) return st;
     return run_fetch_destroy(job, logml_base, logml_full, mu, sigma, info);
+}
+
+// ---------------------------------------------------------------------------------------
+// cached factor
+// ---------------------------------------------------------------------------------------
+struct ngp_factor {
+    ngp_ctx *ctx = nullptr;
+    int P = 0, n = 0;
+    int64_t ldy = 0;
+    std::vector<std::vector<int32_t>> ops;
+    std::vector<std::vector<double>> params;
+    std::vector<ngp_kernel> kernels;      // point into ops / params
+    std::vector<double> t, y;             // y: [P or 1][n] packed
+    int n0 = 0, nb0 = 0;
+    int64_t item_stride = 0;              // (n0 + NGP_MAX_AUX) x n0 doubles
+    double *L = nullptr;                  // [P][item_stride]
+    double *dinv = nullptr;               // [nb0][P][64 x 64]
+    double *logdet = nullptr;             // [P] sum log diag L of the main block
+    int32_t *info = nullptr;              // [P]
+    std::vector<double> logml0;
+    std::vector<int32_t> info0;
+};
+
+namespace {
+
+// run the job of a cached-factor query: only the aux rows are filled and swept
+ngp_status factor_run(ngp_factor *f, ngp_job *j, bool create) {
+    ngp_ctx *c = f->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    JobGeom &g = j->g;
+    g.item_stride = f->item_stride;
+    hipStream_t s = c->stream;
+    const DevSpec sp = dev_spec(c->spec);
+    EventTimer tm(c->profiling, s);
+    const int P = f->P;
+    void *tab = nullptr, *sig = nullptr;
+    if (g.n0 > 0) {
+        if (g.lattice) {
+            ngp_status st = c->alloc(&tab, sizeof(double) * (size_t)g.maxstat * g.R * P);
+            if (!st) st = c->alloc(&sig, sizeof(double) * (size_t)g.maxcp * g.npts * P);
+            if (st) { c->release(tab); c->release(sig); return st; }
+        }
+        ChunkPtrs p{};
+        p.L = f->L;
+        p.dinv = f->dinv;
+        p.progs = j->progs;
+        p.t0 = j->t0;
+        p.taux = j->taux;
+        p.y0 = j->y0;
+        p.logdet = j->logdet;
+        p.info = j->info;
+        p.tab = (double *)tab;
+        p.sig = (double *)sig;
+        p.qpts = j->qpts;
+        const double nrows_aux = (double)g.naux;
+        const size_t mstep = (size_t)P * NB * NB;
+        if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, P, sp, s); });
+        if (create) {
+            HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)P, s));
+            HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)P, s));
+            tm.run(4, 0.0, 8.0 * P * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0),
+                   [&] { launch_fill(g, p, P, sp, s); });
+            factor_chunk(lane_of(c, 0), g, p, P, tm, mstep);
+            HIPCHK(hipMemcpyAsync(f->logdet, j->logdet, sizeof(double) * (size_t)P,
+                                  hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(f->info, j->info, sizeof(int32_t) * (size_t)P,
+                                  hipMemcpyDeviceToDevice, s));
+        } else {
+            HIPCHK(hipMemcpyAsync(j->logdet, f->logdet, sizeof(double) * (size_t)P,
+                                  hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(j->info, f->info, sizeof(int32_t) * (size_t)P,
+                                  hipMemcpyDeviceToDevice, s));
+            tm.run(4, 0.0, 8.0 * P * nrows_aux * g.n0,
+                   [&] { launch_fill(g, p, P, sp, s, /*aux_only=*/true); });
+            // right-looking sweep of the aux rows through the resident factor
+            for (int jj = 0; jj < g.nb0; ++jj) {
+                ChunkPtrs pj = p;
+                pj.dinv = f->dinv + (size_t)jj * mstep;
+                tm.run(0, P * nrows_aux * (double)NB * NB, P * 8.0 * 3.0 * nrows_aux * NB,
+                       [&] { launch_chol_col(g, pj, P, jj, COL_AUX, jj * NB, 0, s); });
+                tm.run(0, P * nrows_aux * 2.0 * NB * (double)(g.n0 - (jj + 1) * NB),
+                       P * 8.0 * (g.n0 - (jj + 1) * NB) * (2.0 * nrows_aux + NB),
+                       [&] { launch_aux_update(g, pj, P, jj, s); });
+            }
+        }
+        tm.run(2, P * nrows_aux * nrows_aux * g.n0, P * 8.0 * nrows_aux * g.n0,
+               [&] { launch_gram(g, f->L, j->G, P, s); });
+    } else {
+        HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)P, s));
+        HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)P, s));
+    }
+    EpiPtrs e{};
+    e.progs = j->progs;
+    e.taux = j->taux;
+    e.G = j->G;
+    e.ya = j->ya;
+    e.logdet = j->logdet;
+    e.info = j->info;
+    e.work = j->work;
+    e.zbuf = j->zbuf;
+    e.logml_base = j->logml_base;
+    e.logml_full = j->logml_full;
+    e.mu = j->mu;
+    e.sigma = j->sigma;
+    e.work_stride = j->work_stride;
+    tm.run(3, 0.0, 0.0, [&] { launch_epilogue(g, e, sp, s); });
+    hipError_t err = hipStreamSynchronize(s);
+    if (err == hipSuccess) err = hipGetLastError();
+    tm.resolve(c->prof);
+    c->release(tab);
+    c->release(sig);
+    if (err != hipSuccess) return (ngp_status)err;
+    j->ran = true;
+    return NGP_OK;
+}
+
+}  // namespace
+
+extern "C" ngp_status ngp_factor_create(ngp_ctx *c, int32_t P, const ngp_kernel *kernels,
+                                        int32_t n, const double *t, const double *y, int64_t ldy,
+                                        ngp_factor **out) {
+    if (!c || !out || !kernels || !t || !y || P <= 0 || n <= 0) return NGP_ERR_ARG;
+    *out = nullptr;
+    for (int i = 0; i < P; ++i) {
+        ngp_status st = check_program(&kernels[i]);
+        if (st) return st;
+    }
+    ngp_factor *f = new (std::nothrow) ngp_factor();
+    if (!f) return NGP_ERR_TOO_LARGE;
+    f->ctx = c;
+    f->P = P;
+    f->n = n;
+    f->ldy = ldy ? n : 0;
+    f->ops.resize((size_t)P);
+    f->params.resize((size_t)P);
+    f->kernels.resize((size_t)P);
+    for (int i = 0; i < P; ++i) {
+        f->ops[(size_t)i].assign(kernels[i].ops, kernels[i].ops + kernels[i].n_ops);
+        f->params[(size_t)i].assign(kernels[i].params, kernels[i].params + kernels[i].n_params);
+        f->kernels[(size_t)i] = kernels[i];
+        f->kernels[(size_t)i].ops = f->ops[(size_t)i].data();
+        f->kernels[(size_t)i].params = f->params[(size_t)i].data();
+    }
+    f->t.assign(t, t + n);
+    const int ny = ldy ? P : 1;
+    f->y.resize((size_t)ny * n);
+    for (int b = 0; b < ny; ++b)
+        for (int i = 0; i < n; ++i) f->y[(size_t)b * n + i] = y[(int64_t)b * ldy + i];
+    f->n0 = (n / NB) * NB;
+    f->nb0 = f->n0 / NB;
+    f->item_stride = (int64_t)(f->n0 + NGP_MAX_AUX) * f->n0;
+    ngp_status st = NGP_OK;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (hipSetDevice(c->device) != hipSuccess) st = NGP_ERR_NO_DEVICE;
+        void *q = nullptr;
+        if (!st && f->n0 > 0) {
+            if (!(st = c->alloc(&q, sizeof(double) * (size_t)f->item_stride * P))) f->L = (double *)q;
+            if (!st && !(st = c->alloc(&q, sizeof(double) * (size_t)f->nb0 * P * NB * NB)))
+                f->dinv = (double *)q;
+        }
+        if (!st && !(st = c->alloc(&q, sizeof(double) * (size_t)P))) f->logdet = (double *)q;
+        if (!st && !(st = c->alloc(&q, sizeof(int32_t) * (size_t)P))) f->info = (int32_t *)q;
+    }
+    ngp_job *job = nullptr;
+    static const double dummy = 0.0;
+    if (!st)
+        st = stage_general(c, P, f->kernels.data(), n, f->t.data(), f->y.data(), f->ldy, 0, &dummy,
+                           1, &dummy, 0, 0, nullptr, 0, &job);
+    if (!st) st = factor_run(f, job, /*create=*/true);
+    f->logml0.resize((size_t)P);
+    f->info0.resize((size_t)P);
+    if (!st) st = ngp_job_fetch(job, nullptr, f->logml0.data(), nullptr, nullptr, f->info0.data());
+    ngp_job_destroy(job);
+    if (st) {
+        ngp_factor_destroy(f);
+        return st;
+    }
+    *out = f;
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_factor_logml(const ngp_factor *f, double *logml, int32_t *info) {
+    if (!f) return NGP_ERR_ARG;
+    for (int i = 0; i < f->P; ++i) {
+        if (logml) logml[i] = f->logml0[(size_t)i];
+        if (info) info[i] = f->info0[(size_t)i];
+    }
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_factor_nowcast(ngp_factor *f, int32_t d, const double *t_add, int32_t D,
+                                         const double *y_add, int32_t m, const double *t_new,
+                                         int32_t noise_on_new, double *logml_base,
+                                         double *logml_full, double *mu, double *sigma,
+                                         int32_t *info) {
+    if (!f || d < 0 || D <= 0 || m < 0) return NGP_ERR_ARG;
+    static const double dummy = 0.0;
+    if (d == 0) { t_add = &dummy; y_add = &dummy; }
+    ngp_job *job = nullptr;
+    ngp_status st = stage_general(f->ctx, f->P, f->kernels.data(), f->n, f->t.data(), f->y.data(),
+                                  f->ldy, d, t_add, D, y_add, 0, m, t_new, noise_on_new, &job);
+    if (st) return st;
+    st = factor_run(f, job, /*create=*/false);
+    if (!st) st = ngp_job_fetch(job, logml_base, logml_full, mu, sigma, info);
+    ngp_job_destroy(job);
+    return st;
+}
+
+extern "C" void ngp_factor_destroy(ngp_factor *f) {
+    if (!f) return;
+    {
+        std::lock_guard<std::mutex> lk(f->ctx->mu);
+        f->ctx->release(f->L);
+        f->ctx->release(f->dinv);
+        f->ctx->release(f->logdet);
+        f->ctx->release(f->info);
+    }
+    delete f;
 }
 
 extern "C" ngp_status ngp_cov_batch(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n1,

@@ -209,12 +209,13 @@ __global__ __launch_bounds__(256) void cov_kernel(const DevProgram *progs, const
 // ---------------------------------------------------------------------------------------
 // fill: K lower blocks + aux rows into the factor storage, one 64x64 tile per workgroup
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fill_kernel(JobGeom g, ChunkPtrs p, int ntri, DevSpec sp) {
+__global__ __launch_bounds__(256) void fill_kernel(JobGeom g, ChunkPtrs p, int ntri, int tile_off,
+                                                   DevSpec sp) {
     __shared__ DevProgram P;
     const int item = blockIdx.y;
     load_program(&P, p.progs + item);
     __syncthreads();
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x + tile_off;   // tile_off = ntri: aux rows only (cached factor)
     int r, c;            // block row / block column
     bool aux = false;
     if (tile < ntri) {   // lower-triangular block (r >= c): tile = r(r+1)/2 + c
@@ -391,12 +392,12 @@ __device__ __forceinline__ double keval_lattice(const DevProgram &P, const doubl
 }
 
 __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs p, int ntri,
-                                                           DevSpec sp) {
+                                                           int tile_off, DevSpec sp) {
     __shared__ DevProgram P;
     const int item = blockIdx.y;
     load_program(&P, p.progs + item);
     __syncthreads();
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x + tile_off;
     int r, c;
     bool aux = false;
     if (tile < ntri) {
@@ -911,7 +912,7 @@ __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, in
 struct ColStep {
     int j;        // block column being finished
     int k0;       // first k not yet accumulated into column j
-    int nmain;    // main row tiles below the diagonal (r = j+1 ...)
+    int nmain;    // main row tiles below the diagonal (r = j+1 ...); 0: aux tiles only
     int ntiles;   // nmain + aux tiles
     int groups;   // workgroups per item
     int ahead;    // unused (the diag-ahead tile has its own kernel)
@@ -1168,6 +1169,35 @@ __global__ __launch_bounds__(64, 2) void diag_ahead_kernel(JobGeom g, ChunkPtrs 
     const double *pd = Ld + (long)r16 * ld + 2 * q;
     gemm_rows<4>(acc4, pd, pd, ld, 0, j * NB);
     subtract_in_place_perm(Ld, ld, (j + 2) * NB, acc4, lane);
+}
+
+// cached factor (ngp_factor_*): L and every M_j stay on the device; a query only needs its aux
+// rows W = X L^-T.  Right-looking sweep over block columns, so each step is wide instead of a
+// long k-loop on a single wave per aux tile:  W_j = C_j M_j' (chol_col_kernel, empty k-range),
+// then this kernel:  C_c -= W_j L_(c,j)'  for every block column c > j, one wave per (aux tile, c).
+__global__ __launch_bounds__(256, 2) void aux_update_kernel(JobGeom g, ChunkPtrs p, int j) {
+    const int item = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntl = g.naux_pad / NB;
+    const int idx = blockIdx.x * 4 + wave;
+    if (idx >= ntl * (g.nb0 - 1 - j)) return;
+    const int a = idx % ntl, c = j + 1 + idx / ntl;
+    const long ld = g.ld;
+    double *Lit = p.L + (long)item * g.item_stride;
+    double *Wa = Lit + ((long)g.n0 + (long)a * NB) * ld;      // aux tile rows (B operand)
+    const double *Lc = Lit + (long)c * NB * ld;               // rows of block c (A operand)
+    const int r16 = lane & 15, q = lane >> 4;
+    double acc4[4][4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[x][y][r] = 0.0;
+    gemm_rows<4>(acc4, Lc + (long)r16 * ld + 2 * q, Wa + (long)r16 * ld + 2 * q, ld, j * NB,
+                 (j + 1) * NB);
+    subtract_in_place_perm(Wa, ld, c * NB, acc4, lane);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1739,14 +1769,17 @@ void launch_tables(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &
     hipLaunchKernelGGL(tables_kernel, dim3(Bc), dim3(256), 0, s, g, p, sp);
 }
 
-void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s) {
+void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s,
+                 bool aux_only) {
     if (g.n0 == 0) return;
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
     const int ntiles = ntri + (g.naux_pad / NB) * g.nb0;
+    const int off = aux_only ? ntri : 0;
     if (g.lattice)
-        hipLaunchKernelGGL(fill_lattice_kernel, dim3(ntiles, Bc), dim3(256), 0, s, g, p, ntri, sp);
+        hipLaunchKernelGGL(fill_lattice_kernel, dim3(ntiles - off, Bc), dim3(256), 0, s, g, p, ntri,
+                           off, sp);
     else
-        hipLaunchKernelGGL(fill_kernel, dim3(ntiles, Bc), dim3(256), 0, s, g, p, ntri, sp);
+        hipLaunchKernelGGL(fill_kernel, dim3(ntiles - off, Bc), dim3(256), 0, s, g, p, ntri, off, sp);
 }
 
 void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int k0, hipStream_t s) {
@@ -1760,7 +1793,7 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
     st.dbg = dbg;
     st.j = j;
     st.k0 = k0;
-    st.nmain = g.nb0 - 1 - j;
+    st.nmain = (mode == COL_AUX) ? 0 : g.nb0 - 1 - j;
     st.ahead = 0;
     st.ntiles = st.nmain + g.naux_pad / NB;
     if (st.ntiles <= 0) return;
@@ -1775,6 +1808,12 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
         hipLaunchKernelGGL(chol_col_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p,
                            Bc, st);
     }
+}
+
+void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {
+    const int n = (g.naux_pad / NB) * (g.nb0 - 1 - j);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(aux_update_kernel, dim3((n + 3) / 4, Bc), dim3(256), 0, s, g, p, j);
 }
 
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {

@@ -164,7 +164,11 @@ def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transform
     y_add = np.stack([model.y_transform.apply(np.asarray(nc.y, dtype=np.float64))
                       for nc in nowcasts])
     t_new = model.ds_transform.apply(autogp.to_days(dates))
-    out = model._eng().nowcast(model.programs(), t, y, t_add, y_add, t_new, True)
+    fac = model._factor()
+    if fac is not None:
+        out = fac.nowcast(t_add, y_add, t_new, True)
+    else:
+        out = model._eng().nowcast(model.programs(), t, y, t_add, y_add, t_new, True)
     bad = np.flatnonzero(out["info"])
     if bad.size:
         raise autogp.PosDefException(int(out["info"][bad[0]]), int(bad[0]))

@@ -150,7 +150,8 @@ def nowcast(program, t, y, t_add, y_add, t_new, noise_on_new=True, spec=None):
     t = np.asarray(t, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64)
     t_add = np.asarray(t_add, dtype=np.float64)
-    y_add = np.asarray(y_add, dtype=np.float64).reshape(-1, t_add.size)
+    y_add = (np.asarray(y_add, dtype=np.float64).reshape(-1, t_add.size) if t_add.size
+             else np.zeros((1, 0)))
     lb, info = logml(program, t, y, spec)
     tt = np.concatenate([t, t_add])
     lf, mus, sigma = [], [], None

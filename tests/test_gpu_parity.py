@@ -155,6 +155,65 @@ def test_nowcast_fan_out_vs_per_scenario_refactorisation(ctx, n, d, m, D, P):
         assert np.array_equal(out["sigma"][p], out["sigma"][p].T)
 
 
+@pytest.mark.parametrize("n,lattice", [(40, True), (128, True), (200, True), (333, False),
+                                       (1100, True)])
+def test_cached_factor_queries_match_refactorisation_and_oracle(ctx, n, lattice):
+    """ngp_factor_*: L stays on the device; every query (plain predict, nowcast fan-out, another
+    horizon) must equal the one-shot entry point that refactorises, and the oracle."""
+    w = make_workload("C1", n=n, P=4, D=5, d=2, m=7, seed_offset=7 * n)
+    t = w.t if lattice else np.sort(np.random.Generator(np.random.PCG64(n)).uniform(0, 1, n))
+    t_add = w.t_add if lattice else t[-1] + np.array([0.013, 0.031])
+    t_new = w.t_new if lattice else t_add[-1] + 0.01 * np.arange(1, 8) ** 1.3
+    f = ctx.factor(w.programs, t, w.y)
+    lm0, info0 = f.logml()
+    ref_lm, ref_info = ctx.logml_batch(w.programs, t, w.y)
+    assert not info0.any() and not ref_info.any()
+    assert np.allclose(lm0, ref_lm, rtol=1e-12, atol=1e-9)
+    queries = [(t_add, w.y_add, t_new), (np.zeros(0), np.zeros((1, 0)), t_new[:3]),
+               (t_add[:1], w.y_add[:2, :1], t_new), (t_add, w.y_add, np.zeros(0))]
+    for ta, ya, tn in queries:
+        got = f.nowcast(ta, ya, tn)
+        ref = ctx.nowcast_batch(w.programs, t, w.y, ta, ya, tn)
+        assert not got["info"].any()
+        for key in ("logml_base", "logml_full", "mu", "sigma"):
+            if ref[key] is None:
+                assert got[key] is None
+                continue
+            assert nerr(got[key], ref[key]) < 1e-9, (key, n)
+        if tn.size == 0:
+            continue
+        for p, prog in enumerate(w.programs):
+            tt = np.concatenate([t, ta])
+            cond = np.linalg.cond(oracle_np.cov(prog, tt, tt, True))
+            lb, lf, mu, sg, _ = oracle_np.nowcast(prog, t, w.y, ta, ya, tn)
+            assert nerr(got["logml_base"][p], lb) < tol(TOL_LOGML, cond)
+            assert nerr(got["logml_full"][p], lf) < tol(TOL_LOGML, cond)
+            assert nerr(got["mu"][p], mu) < tol(TOL_PRED, cond)
+            assert nerr(got["sigma"][p], sg) < tol(TOL_PRED, cond)
+    f.close()
+
+
+def test_cached_factor_per_item_data_and_limits(ctx):
+    w = make_workload("C1", n=150, P=3, D=2, d=1, m=4)
+    Y = np.stack([w.y, 0.5 * w.y + 0.1, -w.y])
+    f = ctx.factor(w.programs, w.t, Y)
+    mu, sg, lm, info = f.predict(w.t_new)
+    rmu, rsg, rlm, rinfo = ctx.predict_batch(w.programs, w.t, Y, w.t_new)
+    assert not info.any() and nerr(mu, rmu) < 1e-9 and nerr(sg, rsg) < 1e-9 and nerr(lm, rlm) < 1e-9
+    with pytest.raises(_lib.NgpError):            # more aux rows than the handle has room for
+        f.predict(w.t_new[-1] + 0.01 * np.arange(1, 400))
+    # a failing particle keeps its info through queries
+    bad = gp.to_program(gp.SquaredExponential(0.5, 1.0)) + (0.0,)
+    ctx.set_spec(NgpSpec(0, 0, 0, 0, 0.0))
+    t = np.arange(100) / 100
+    t[40] = t[39]
+    fb = ctx.factor([bad, w.programs[0]], t, np.ones(100))
+    _, info0 = fb.logml()
+    q = fb.nowcast(np.zeros(0), np.zeros((1, 0)), np.array([1.1, 1.2]))
+    assert info0[0] > 0 and info0[1] == 0 and q["info"][0] > 0 and q["info"][1] == 0
+    ctx.set_spec(NgpSpec(0, 0, 0, 0, 1e-5))
+
+
 def test_noise_on_new_flag(ctx):
     w = make_workload("C1", n=90, P=2, D=1, d=1, m=4)
     a = ctx.predict_batch(w.programs, w.t, w.y, w.t_new, noise_on_new=True)[1]

@@ -61,3 +61,40 @@ def test_many_particles_concurrent_callers(eng):
     [t.start() for t in th]
     [t.join(timeout=300) for t in th]
     assert not errs and all(o is not None and o.shape == (2, 8) and np.isfinite(o).all() for o in out)
+
+
+def test_repeated_forecasts_reuse_the_resident_factor(eng):
+    """A fitted model queried again (another horizon, a nowcast fan-out) must not refactorise:
+    the mirror keeps one ngp_factor per (particles, data) and the answers equal the one-shot
+    engine path that has no cache."""
+    import numpy as np
+    from nowcastautogp_amd import nowcast as nc
+
+    class NoCache:   # same device library, but every call factorises from scratch
+        def __init__(self, inner):
+            self.ctx = inner.ctx
+            for name in ("logml", "logml_grad", "predict", "nowcast"):
+                setattr(self, name, getattr(inner, name))
+
+    base, multi = mc.nowcast_fixture(eng)
+    d1 = autogp.predict_mvn(base, mc.days(12, 15))
+    handle = base._fcache.factor
+    d2 = autogp.predict_mvn(base, mc.days(12, 20))
+    assert base._fcache.factor is handle and handle is not None
+    plain = autogp.GPModel.from_dict(base.to_dict(), engine=NoCache(eng))
+    r1 = autogp.predict_mvn(plain, mc.days(12, 15))
+    r2 = autogp.predict_mvn(plain, mc.days(12, 20))
+    assert "_fcache" not in plain.__dict__ or plain._fcache.factor is None
+    for got, ref in ((d1, r1), (d2, r2)):
+        assert np.allclose(got.means, ref.means, rtol=1e-9, atol=1e-12)
+        assert np.allclose(got.covs, ref.covs, rtol=1e-9, atol=1e-12)
+    snap = base.to_dict()   # same particles, same rng state
+    a = nc.forecast_with_nowcasts(base, multi, mc.days(12, 14), 5)
+    assert base._fcache.factor is handle
+    plain2 = autogp.GPModel.from_dict(snap, engine=NoCache(eng))
+    b = nc.forecast_with_nowcasts(plain2, multi, mc.days(12, 14), 5)
+    assert a.shape == b.shape and np.allclose(a, b, rtol=1e-8, atol=1e-10)
+    # a move that changes the particles misses the cache
+    autogp.mcmc_parameters(base, 1)
+    autogp.predict_mvn(base, mc.days(12, 15))
+    assert base._fcache.factor is not handle
