@@ -135,6 +135,47 @@ function nowcast_batch(c::Context, progs::Vector{Program}, t::Vector{Float64}, y
     return (logml_base = lb, logml_full = lf, mu = mu, sigma = sigma, info = info)
 end
 
+"""
+Resident factor (include/ngp.h `ngp_factor_*`): factorise the ensemble on its training data once,
+then every `predict_mvn` / `add_data!` fan-out on the same fitted model only sweeps its own rows
+through the L kept on the device.
+"""
+mutable struct Factor
+    h::Ptr{Cvoid}
+    P::Int
+    ctx::Context            # keeps the context alive for as long as the handle
+    function Factor(c::Context, progs::Vector{Program}, t::Vector{Float64}, y::VecOrMat{Float64})
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        n = length(t)
+        ldy = y isa Vector ? 0 : n
+        GC.@preserve progs begin
+            ks = kernels(progs)
+            check(ccall((:ngp_factor_create, LIBNGP), Int32,
+                        (Ptr{Cvoid}, Int32, Ptr{NgpKernel}, Int32, Ptr{Float64}, Ptr{Float64}, Int64,
+                         Ref{Ptr{Cvoid}}), c.h, length(progs), ks, n, t, y, ldy, r),
+                  "ngp_factor_create")
+        end
+        f = new(r[], length(progs), c)
+        finalizer(x -> ccall((:ngp_factor_destroy, LIBNGP), Cvoid, (Ptr{Cvoid},), x.h), f)
+        return f
+    end
+end
+
+function nowcast(f::Factor, t_add::Vector{Float64}, y_add::Matrix{Float64}, t_new::Vector{Float64};
+                 noise_on_new::Bool = true)
+    P, d, D, m = f.P, length(t_add), max(size(y_add, 2), 1), length(t_new)
+    lb, lf = Vector{Float64}(undef, P), Matrix{Float64}(undef, D, P)
+    mu = Array{Float64}(undef, m, D, P)
+    sigma = Array{Float64}(undef, m, m, P)
+    info = zeros(Int32, P)
+    check(ccall((:ngp_factor_nowcast, LIBNGP), Int32,
+                (Ptr{Cvoid}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32, Ptr{Float64}, Int32,
+                 Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                f.h, d, t_add, D, y_add, m, t_new, noise_on_new, lb, lf, mu, sigma, info),
+          "ngp_factor_nowcast")
+    return (logml_base = lb, logml_full = lf, mu = mu, sigma = sigma, info = info)
+end
+
 function weights_normalize(logw::Vector{Float64})
     w = similar(logw); ess = Ref(0.0); ln = Ref(0.0)
     check(ccall((:ngp_weights_normalize, LIBNGP), Int32,
