@@ -10,15 +10,20 @@
 //   covariance) is Schur-complement algebra on the small Gram matrix G = W W'.
 //
 // Kernels (roofline class):
-//   fill_kernel       RPN kernel-tree interpreter, one 64x64 tile per workgroup, 512-B row
+//   tables_kernel / fill_lattice_kernel   table-driven covariance fill on lattice times
+//   fill_kernel       direct RPN kernel-tree interpreter, one 64x64 tile per workgroup, 512-B row
 //                     stores                                   (HBM-write + fp64 transcendental VALU)
-//   chol_diag_kernel  C_jj -= L_j L_j' (MFMA), 64x64 Cholesky in LDS, 16x16 diagonal-block
-//                     inverses                                              (latency-bound)
-//   chol_col_kernel   C_rj -= L_r L_j' over k = 64 j (v_mfma_f64_16x16x4_f64, 64x64 tile per
-//                     wave), then the 64-wide triangular solve as MFMA block substitution on the
-//                     accumulator tiles without leaving registers    (fp64-MFMA-bound; dominant)
+//   chol_diag_kernel  C_jj -= L_j L_j' (MFMA), 64x64 Cholesky four pivots per barrier round on
+//                     packed lower-triangular LDS tiles, full inverse M = L_jj^-1 in MFMA strip
+//                     order                                                 (latency-bound)
+//   chol_col_glds_kernel / chol_col_kernel   C_rj -= L_r L_j' (v_mfma_f64_4x4x4_4b_f64 composite,
+//                     64x64 tile per wave, LDS-DMA staged operands on the long k-loops), then the
+//                     64-wide solve L_rj = C_rj M' on the accumulators (fp64-MFMA-bound; dominant)
+//   diag_ahead_kernel pre-accumulation of the next-but-one diagonal tile on a side stream
 //   gram_kernel       G = W W'                                              (HBM-read-bound, small)
 //   epilogue_kernel   dense Schur algebra per item + per-scenario solves     (latency-bound, tiny)
+//   grad_*            K^-1 = W_I W_I' (MFMA), reverse-mode contraction with aa' - K^-1
+//   aux_update_kernel right-looking sweep of the aux rows through a resident factor
 //
 // MFMA operand maps used throughout (v_mfma_f64_16x16x4_f64, guide cdna_hip_programming.md §3):
 //   A: lane l holds A[m = l&15][k = l>>4]     B: lane l holds B[k = l>>4][n = l&15]
