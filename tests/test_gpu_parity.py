@@ -299,6 +299,39 @@ def test_headline_size_2048_properties_and_spot_parity(ctx):
         assert nerr(out["sigma"][p], sg) < tol(TOL_PRED, cond)
 
 
+def test_headline_size_2048_gradient_and_resident_factor(ctx):
+    """Headline length again, for the two paths the oracle is too slow to follow there: the
+    gradient (checked as a directional derivative against central differences of the library's own
+    logml, both n = 2048) and the resident factor (must reproduce the one-shot fan-out)."""
+    w = make_workload("C3", P=6, D=5)
+    lm, grads, info = ctx.logml_grad_batch(w.programs, w.t, w.y)
+    assert not info.any()
+    lm0, _ = ctx.logml_batch(w.programs, w.t, w.y)
+    assert nerr(lm, lm0) < 1e-11
+    rng = np.random.Generator(np.random.PCG64(5))
+    eps = 1e-6
+    plus, minus, dirs = [], [], []
+    for ops, params, noise in w.programs:
+        theta = np.concatenate([params, [noise]])
+        dlt = rng.standard_normal(theta.size) * np.maximum(np.abs(theta), 1e-3)
+        dirs.append(dlt)
+        a, b = theta + eps * dlt, theta - eps * dlt
+        plus.append((ops, a[:-1], float(a[-1])))
+        minus.append((ops, b[:-1], float(b[-1])))
+    lp, _ = ctx.logml_batch(plus, w.t, w.y)
+    lmn, _ = ctx.logml_batch(minus, w.t, w.y)
+    for k in range(len(w.programs)):
+        fd = (lp[k] - lmn[k]) / (2 * eps)
+        an = float(grads[k] @ dirs[k])
+        assert abs(fd - an) <= 2e-5 * max(1.0, abs(an), np.linalg.norm(grads[k] * dirs[k])), (k, fd, an)
+    f = ctx.factor(w.programs, w.t, w.y)
+    got = f.nowcast(w.t_add, w.y_add, w.t_new)
+    ref = ctx.nowcast_batch(w.programs, w.t, w.y, w.t_add, w.y_add, w.t_new)
+    for key in ("logml_base", "logml_full", "mu", "sigma"):
+        assert nerr(got[key], ref[key]) < 1e-9, key
+    f.close()
+
+
 def test_gradient_matches_oracle_on_golden(ctx, golden):
     """d logml / d(theta, noise) = 1/2 tr((aa' - K^-1) dK): GPU (identity aux rows -> K^-1 by MFMA
     Gram, reverse-mode tree sweep) vs the C oracle's forward-mode analytic gradient.  Stated
