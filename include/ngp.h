@@ -226,9 +226,10 @@ void       ngp_factor_destroy(ngp_factor *f);
 
 /* ---- measurement hooks -----------------------------------------------------
  * HIP-event timing of the kernels a job launches, on the stream they are
- * launched on.  Classes: 0 = chol_col (trailing-update GEMM + fused solve, the
- * dominant kernel), 1 = chol_diag, 2 = gram, 3 = epilogue, 4 = cov fill,
- * 5 = gradient kernels.                                                       */
+ * launched on.  Classes: 0 = chol_col_glds_kernel (fat steps: trailing-update
+ * GEMM + fused solve, the dominant kernel), 1 = chol_diag, 2 = gram,
+ * 3 = epilogue, 4 = cov fill, 5 = gradient kernels, 6 = chol_col_kernel (thin /
+ * full steps, aux solves of a resident factor), 7 = aux_update_kernel.        */
 #define NGP_NUM_KERNEL_CLASSES 8
 typedef struct ngp_profile {
     double   ms[NGP_NUM_KERNEL_CLASSES];       /* summed device time per class */
