@@ -89,9 +89,14 @@ def fit_forecast_wallclock(w, device):
     scen = nc.create_nowcast_data([row for row in w.y_add], dates[n:n + d])
     t0 = time.perf_counter()
     fc = nc.forecast_with_nowcasts(model, scen, dates[n + d:], 20)
-    t_fc = time.perf_counter() - t0
+    t_fc = time.perf_counter() - t0     # first call: factorises the fitted ensemble once
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fc = nc.forecast_with_nowcasts(model, scen, dates[n + d:], 20)
+    t_fc_again = (time.perf_counter() - t0) / 3   # factor resident, device mixture sampler
     ok = bool(np.isfinite(fc).all()) and fc.shape == (m, D * 20)
-    return {"fit_s": t_fit, "forecast_with_nowcasts_s": t_fc, "n": n, "particles": P,
+    return {"fit_s": t_fit, "forecast_with_nowcasts_s": t_fc,
+            "forecast_with_nowcasts_again_s": t_fc_again, "n": n, "particles": P,
             "scenarios": D, "draws_per_scenario": 20, "settings": {k: v for k, v in settings.items()},
             "finite_and_shaped": ok}
 

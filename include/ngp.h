@@ -198,6 +198,24 @@ ngp_status ngp_job_fetch(ngp_job *job, double *logml_base, double *logml_full,
                          double *mu, double *sigma, int32_t *info);
 void       ngp_job_destroy(ngp_job *job);
 
+/* ---- mixture sampling on the device -------------
+ * predict_mvn(...) |> rand of the reference (src/forecasting.jl:160, 180) for S
+ * mixtures over the same P components at once (S = nowcast scenarios): component
+ * k ~ Categorical(w[s][.]), then  mu[k][s][.] + chol(sigma[k]) z,  z ~ N(0, I).
+ *   w     [S x P]      mixture weights, each row sums to 1 (ngp_weights_normalize)
+ *   mu    [P x S x m]  component means   (layout of ngp_nowcast_batch's mu)
+ *   sigma [P x m x m]  component covariances, shared by the S mixtures
+ *   out   [S x draws x m]; comp [S x draws] (may be NULL) the component drawn;
+ *   info  [P] (may be NULL): 0, or the first non-positive pivot of chol(sigma[k])
+ * Randomness: Philox4x32-10 (counter = (draw, scenario, block, 0), key = seed):
+ * reproducible for a given seed on any device and by the numpy restatement in
+ * oracle/, NOT against Julia's Xoshiro stream — the reference's own tests only
+ * check shapes and ranges of draws.  m <= NGP_MAX_AUX.     */
+ngp_status ngp_mixture_sample(ngp_ctx *ctx, int32_t P, int32_t S, int32_t m,
+                              const double *w, const double *mu, const double *sigma,
+                              int32_t draws, uint64_t seed,
+                              double *out, int32_t *comp, int32_t *info);
+
 /* ---- cached factor ------------------------------
  * A fitted model is queried many times with the same particles and the same
  * training data: forecast() on several date grids, forecast_with_nowcasts()

@@ -176,6 +176,22 @@ function nowcast(f::Factor, t_add::Vector{Float64}, y_add::Matrix{Float64}, t_ne
     return (logml_base = lb, logml_full = lf, mu = mu, sigma = sigma, info = info)
 end
 
+"Draws from S mixtures over the same components on the device (include/ngp.h `ngp_mixture_sample`)."
+function mixture_sample(c::Context, w::Matrix{Float64},        # P x S  (column = scenario)
+                        mu::Array{Float64,3},                   # m x S x P
+                        sigma::Array{Float64,3},                # m x m x P
+                        draws::Integer, seed::UInt64)
+    P, S, m = size(w, 1), size(w, 2), size(mu, 1)
+    out = Array{Float64}(undef, m, draws, S)
+    info = zeros(Int32, P)
+    check(ccall((:ngp_mixture_sample, LIBNGP), Int32,
+                (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
+                 UInt64, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+                c.h, P, S, m, w, mu, sigma, draws, seed, out, C_NULL, info), "ngp_mixture_sample")
+    raise_if_not_posdef(info)
+    return out
+end
+
 function weights_normalize(logw::Vector{Float64})
     w = similar(logw); ess = Ref(0.0); ln = Ref(0.0)
     check(ccall((:ngp_weights_normalize, LIBNGP), Int32,

@@ -29,7 +29,7 @@ SYMBOLS = (
     "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
     "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
-    "ngp_factor_destroy", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
+    "ngp_factor_destroy", "ngp_mixture_sample", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
     "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
 )
 
@@ -94,6 +94,8 @@ def load():
         "ngp_factor_nowcast": (i32, [vp, i32, f64p, i32, f64p, i32, f64p, i32, f64p, f64p, f64p,
                                      f64p, i32p]),
         "ngp_factor_destroy": (None, [vp]),
+        "ngp_mixture_sample": (i32, [vp, i32, i32, i32, f64p, f64p, f64p, i32, C.c_uint64, f64p,
+                                     i32p, i32p]),
         "ngp_profile_enable": (i32, [vp, i32]),
         "ngp_profile_reset": (i32, [vp]),
         "ngp_profile_get": (i32, [vp, C.POINTER(NgpProfile)]),
@@ -327,6 +329,22 @@ class Context:
         _chk(load().ngp_factor_create(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy,
                                       C.byref(h)), "ngp_factor_create")
         return Factor(self, h, ka.n)
+
+    def mixture_sample(self, w, mu, sigma, draws: int, seed: int):
+        """S mixtures over the same P components, sampled on the device (``ngp_mixture_sample``):
+        w [S,P], mu [P,S,m], sigma [P,m,m] -> (out [S,draws,m], comp [S,draws], info [P])."""
+        w, mu, sigma = as_f64(w), as_f64(mu), as_f64(sigma)
+        S, P = w.shape
+        m = mu.shape[2]
+        if mu.shape != (P, S, m) or sigma.shape != (P, m, m):
+            raise ValueError("mixture_sample: w [S,P], mu [P,S,m], sigma [P,m,m]")
+        out = np.empty((S, int(draws), m))
+        comp = np.zeros((S, int(draws)), dtype=np.int32)
+        info = np.zeros(P, dtype=np.int32)
+        _chk(load().ngp_mixture_sample(self._h, P, S, m, dptr(w), dptr(mu), dptr(sigma),
+                                       int(draws), C.c_uint64(int(seed) & (2**64 - 1)), dptr(out),
+                                       iptr(comp), iptr(info)), "ngp_mixture_sample")
+        return out, comp, info
 
     def logml_grad_batch(self, programs, t, y):
         ka = KernelArray(programs)

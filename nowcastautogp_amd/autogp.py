@@ -65,6 +65,11 @@ class HipEngine:
     def nowcast(self, programs, t, y, t_add, y_add, t_new, noise_on_new=True):
         return self.ctx.nowcast_batch(programs, t, y, t_add, y_add, t_new, noise_on_new)
 
+    def mixture_sample(self, w, mu, sigma, draws, seed):
+        """Draws from S mixtures over the same components on the device (Philox stream keyed by
+        ``seed``; see include/ngp.h ``ngp_mixture_sample``)."""
+        return self.ctx.mixture_sample(w, mu, sigma, draws, seed)
+
     def factor(self, programs, t, y):
         """Factorise once, keep L on the device (``ngp_factor``): repeated forecasts of a fitted
         model only pay for their appended / forecast rows."""
@@ -529,10 +534,11 @@ class MixtureMVN:
     """Weighted mixture of per-particle multivariate normals (what predict_mvn returns);
     ``rand(k)`` -> [m, k], ``rand()`` -> [m] (reference src/forecasting.jl:160,180)."""
 
-    def __init__(self, means, covs, weights, rng):
+    def __init__(self, means, covs, weights, rng, sampler=None):
         self.means, self.covs = np.asarray(means, float), np.asarray(covs, float)
         self.weights = np.asarray(weights, float) / np.sum(weights)
         self.rng = rng
+        self.sampler = sampler     # engine.mixture_sample: many draws in one device call
         self._chol = {}
 
     def _factor(self, k):
@@ -546,6 +552,14 @@ class MixtureMVN:
     def rand(self, draws: Optional[int] = None):
         m = self.means.shape[1]
         k = 1 if draws is None else int(draws)
+        if self.sampler is not None and draws is not None and k > 1 and m > 0:
+            seed = int(self.rng.integers(0, 2**63 - 1))
+            out, _, info = self.sampler(self.weights[None, :], self.means[:, None, :], self.covs,
+                                        k, seed)
+            bad = np.flatnonzero(info)
+            if bad.size:
+                raise PosDefException(int(info[bad[0]]), int(bad[0]))
+            return np.ascontiguousarray(out[0].T)
         comp = self.rng.choice(self.weights.size, size=k, p=self.weights)
         out = np.empty((m, k))
         for j, c in enumerate(comp):
@@ -576,4 +590,4 @@ def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
         covs = distributed.all_gather_rows(covs.reshape(covs.shape[0], -1)).reshape(
             (-1,) + covs.shape[1:])
         w = distributed.all_gather_rows(w[:, None])[:, 0]
-    return MixtureMVN(means, covs, w, model.rng)
+    return MixtureMVN(means, covs, w, model.rng, getattr(model._eng(), "mixture_sample", None))

@@ -1246,6 +1246,47 @@ extern "C" ngp_status ngp_weights_normalize(int32_t P, const double *logw, doubl
     return NGP_OK;
 }
 
+extern "C" ngp_status ngp_mixture_sample(ngp_ctx *c, int32_t P, int32_t S, int32_t m,
+                                         const double *w, const double *mu, const double *sigma,
+                                         int32_t draws, uint64_t seed, double *out, int32_t *comp,
+                                         int32_t *info) {
+    if (!c || !w || !mu || !sigma || !out || P <= 0 || S <= 0 || m <= 0 || draws <= 0)
+        return NGP_ERR_ARG;
+    if (m > NGP_MAX_AUX) return NGP_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t nw = (size_t)S * P, nmu = (size_t)P * S * m, nsg = (size_t)P * m * m,
+                 nout = (size_t)S * draws * m, ncomp = (size_t)S * draws;
+    void *dw = nullptr, *dmu = nullptr, *dsg = nullptr, *dout = nullptr, *dcomp = nullptr,
+         *dinfo = nullptr;
+    auto freeall = [&] {
+        c->release(dw); c->release(dmu); c->release(dsg); c->release(dout); c->release(dcomp);
+        c->release(dinfo);
+    };
+    ngp_status st;
+    if ((st = c->alloc(&dw, 8 * nw)) || (st = c->alloc(&dmu, 8 * nmu)) ||
+        (st = c->alloc(&dsg, 8 * nsg)) || (st = c->alloc(&dout, 8 * nout)) ||
+        (st = c->alloc(&dcomp, 4 * ncomp)) || (st = c->alloc(&dinfo, 4 * (size_t)P))) {
+        freeall();
+        return st;
+    }
+    hipError_t e = hipMemcpyAsync(dw, w, 8 * nw, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dmu, mu, 8 * nmu, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dsg, sigma, 8 * nsg, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        launch_mixture_sample(P, S, m, (const double *)dw, (const double *)dmu, (double *)dsg, draws,
+                              seed, (double *)dout, (int32_t *)dcomp, (int32_t *)dinfo, s);
+        e = hipMemcpyAsync(out, dout, 8 * nout, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess && comp) e = hipMemcpyAsync(comp, dcomp, 4 * ncomp, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && info) e = hipMemcpyAsync(info, dinfo, 4 * (size_t)P, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    freeall();
+    return e == hipSuccess ? NGP_OK : (ngp_status)e;
+}
+
 // ---------------------------------------------------------------------------------------
 // microbenchmarks / self tests
 // ---------------------------------------------------------------------------------------

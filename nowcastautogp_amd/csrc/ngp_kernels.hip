@@ -1697,6 +1697,108 @@ __global__ __launch_bounds__(128) void grad_reduce_kernel(JobGeom g, const DevPr
 }
 
 // ---------------------------------------------------------------------------------------
+// mixture sampling (ngp_mixture_sample)
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11):
+// counter-based, so draw d of scenario s is a pure function of (seed, s, d) — no state to
+// carry, any launch geometry gives the same stream.
+struct Philox4 { unsigned x, y, z, w; };
+__host__ __device__ inline Philox4 philox4x32_10(Philox4 c, unsigned k0, unsigned k1) {
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c.x, p1 = 0xCD9E8D57ull * c.z;
+        const Philox4 n{(unsigned)(p1 >> 32) ^ c.y ^ k0, (unsigned)p1,
+                        (unsigned)(p0 >> 32) ^ c.w ^ k1, (unsigned)p0};
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+// 53-bit uniform in (0, 1) from two 32-bit words
+__host__ __device__ inline double u01(unsigned hi, unsigned lo) {
+    const unsigned long long v = (((unsigned long long)hi << 32) | lo) >> 11;
+    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// in-place lower Cholesky of one m x m matrix per workgroup (row-major, upper part zeroed)
+__global__ __launch_bounds__(256) void small_chol_kernel(double *A, int m, int32_t *info) {
+    double *a = A + (long)blockIdx.x * m * m;
+    __shared__ double piv;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int k = 0; k < m; ++k) {
+        if (tid == 0) {
+            const double akk = a[(long)k * m + k];
+            if (!(akk > 0.0) && bad == 0) bad = k + 1;
+            piv = sqrt(akk);
+            a[(long)k * m + k] = piv;
+        }
+        __syncthreads();
+        const double d = piv;
+        for (int i = k + 1 + tid; i < m; i += 256) a[(long)i * m + k] /= d;
+        __syncthreads();
+        // trailing update, lower part: element (i, j), k < j <= i
+        const int nt = m - k - 1;
+        for (int e = tid; e < nt * nt; e += 256) {
+            const int i = k + 1 + e / nt, j = k + 1 + e % nt;
+            if (j <= i) a[(long)i * m + j] -= a[(long)i * m + k] * a[(long)j * m + k];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < m * m; e += 256)
+        if (e % m > e / m) a[e] = 0.0;
+    if (tid == 0 && info) info[blockIdx.x] = bad;
+}
+
+// one thread per (scenario, draw)
+__global__ __launch_bounds__(256) void mixture_sample_kernel(int P, int S, int m, const double *w,
+                                                             const double *mu, const double *chol,
+                                                             int draws, unsigned k0, unsigned k1,
+                                                             double *out, int32_t *comp) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)S * draws) return;
+    const int s = (int)(idx / draws), d = (int)(idx % draws);
+    // block 0: component pick by inverse CDF over the P weights of scenario s
+    const Philox4 r0 = philox4x32_10(Philox4{(unsigned)d, (unsigned)s, 0u, 0u}, k0, k1);
+    const double u = u01(r0.x, r0.y);
+    const double *ws = w + (long)s * P;
+    int k = P - 1;
+    double acc = 0.0;
+    for (int i = 0; i < P; ++i) {
+        acc += ws[i];
+        if (u < acc) { k = i; break; }
+    }
+    if (comp) comp[idx] = k;
+    // blocks 1..: four words -> one Box-Muller pair -> two normals
+    const double *L = chol + (long)k * m * m;
+    const double *mk = mu + ((long)k * S + s) * m;
+    double *o = out + idx * m;
+    for (int i = 0; i < m; ++i) o[i] = mk[i];
+    for (int j0 = 0; j0 < m; j0 += 2) {
+        const Philox4 r = philox4x32_10(Philox4{(unsigned)d, (unsigned)s, (unsigned)(1 + j0 / 2), 0u},
+                                        k0, k1);
+        const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
+        const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
+        const double z0 = rad * cos(ang), z1 = rad * sin(ang);
+        for (int i = j0; i < m; ++i) o[i] += L[(long)i * m + j0] * z0;          // column j0 of L
+        if (j0 + 1 < m)
+            for (int i = j0 + 1; i < m; ++i) o[i] += L[(long)i * m + j0 + 1] * z1;
+    }
+}
+
+void launch_mixture_sample(int P, int S, int m, const double *w, const double *mu, double *chol,
+                           int draws, uint64_t seed, double *out, int32_t *comp, int32_t *info,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(small_chol_kernel, dim3(P), dim3(256), 0, s, chol, m, info);
+    const long n = (long)S * draws;
+    hipLaunchKernelGGL(mixture_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P,
+                       S, m, w, mu, (const double *)chol, draws, (unsigned)seed,
+                       (unsigned)(seed >> 32), out, comp);
+}
+
+// ---------------------------------------------------------------------------------------
 // microbenchmarks / self tests
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mfma_bench_kernel(double *out, int iters) {

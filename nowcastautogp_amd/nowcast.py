@@ -103,6 +103,15 @@ def make_and_fit_model(data: TData, *, n_particles: int = 1, smc_data_proportion
 
 
 def _apply(inv_transformation: Callable, a: np.ndarray) -> np.ndarray:
+    """Elementwise ``inv_transformation.(a)`` (reference src/forecasting.jl:161).  Callables that
+    already map arrays elementwise (identity, ``np.exp``, Box-Cox inverses) are applied in one go;
+    scalar-only ones (``math.exp``, branches on the value) go through ``np.vectorize``."""
+    try:
+        out = np.asarray(inv_transformation(a), dtype=np.float64)
+        if out.shape == a.shape:
+            return out
+    except Exception:
+        pass
     return np.vectorize(inv_transformation, otypes=[np.float64])(a)
 
 
@@ -176,8 +185,29 @@ def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transform
     covs = out["sigma"] / (s * s)
     P = len(model.particles)
     rng = model.rng
-    res = np.empty((len(dates), len(nowcasts) * draws))
-    for sc in range(len(nowcasts)):
+    D = len(nowcasts)
+    sampler = getattr(model._eng(), "mixture_sample", None)
+    if sampler is not None and len(dates) > 0:
+        # every scenario at once: add_data! weight update, maybe_resample! (ancestors ~ w, weights
+        # -> ancestor counts / P), then ONE device call that draws from all D mixtures
+        logw = model.log_weights[None, :] + (out["logml_full"].T - out["logml_base"][None, :])
+        mx = logw.max(axis=1, keepdims=True)
+        w = np.exp(logw - mx)
+        w /= w.sum(axis=1, keepdims=True)
+        ess = 1.0 / np.sum(w * w, axis=1)
+        low = ess < ess_threshold * P
+        if low.any():
+            w[low] = rng.multinomial(P, w[low]) / P
+        means = (out["mu"] - b) / s                                   # [P, D, m]
+        seed = int(rng.integers(0, 2**63 - 1))
+        smp, _, info = sampler(w, means, covs, int(draws), seed)      # [D, draws, m]
+        bad = np.flatnonzero(info)
+        if bad.size:
+            raise autogp.PosDefException(int(info[bad[0]]), int(bad[0]))
+        res = smp.reshape(D * int(draws), len(dates)).T
+        return _apply(inv_transformation, np.ascontiguousarray(res))
+    res = np.empty((len(dates), D * draws))
+    for sc in range(D):
         logw = model.log_weights + (out["logml_full"][:, sc] - out["logml_base"])
         from . import _lib
         w, ess, _ = _lib.weights_normalize(logw)

@@ -192,3 +192,59 @@ def weights_normalize(logw):
     e = np.exp(logw - mx)
     w = e / e.sum()
     return w, float(1.0 / np.sum(w * w)), float(mx + math.log(e.sum()))
+
+
+# ---------------------------------------------------------------------------------------------
+# mixture sampling (include/ngp.h ngp_mixture_sample; reference src/forecasting.jl:160,180 draws
+# with Julia's RNG, which nothing here can reproduce — this restates the LIBRARY's stream)
+# ---------------------------------------------------------------------------------------------
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al. SC'11).  ctr [..., 4], key [..., 2] uint32 -> [..., 4]."""
+    c = np.array(ctr, dtype=np.uint64).copy()
+    k = np.array(key, dtype=np.uint64).copy()
+    c, k = np.broadcast_arrays(c, np.zeros(c.shape[:-1] + (1,), np.uint64))[0].copy(), \
+        np.broadcast_to(k, c.shape[:-1] + (2,)).copy()
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[..., 0]
+        p1 = np.uint64(0xCD9E8D57) * c[..., 2]
+        n = np.stack([(p1 >> np.uint64(32)) ^ c[..., 1] ^ k[..., 0], p1 & m32,
+                      (p0 >> np.uint64(32)) ^ c[..., 3] ^ k[..., 1], p0 & m32], axis=-1)
+        c = n & m32
+        k = np.stack([(k[..., 0] + np.uint64(0x9E3779B9)) & m32,
+                      (k[..., 1] + np.uint64(0xBB67AE85)) & m32], axis=-1)
+    return c.astype(np.uint32)
+
+
+def _u01(hi, lo):
+    v = ((hi.astype(np.uint64) << np.uint64(32)) | lo.astype(np.uint64)) >> np.uint64(11)
+    return (v.astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def mixture_sample(w, mu, sigma, draws, seed):
+    """w [S,P], mu [P,S,m], sigma [P,m,m] -> out [S,draws,m], comp [S,draws]."""
+    w, mu, sigma = (np.asarray(a, dtype=np.float64) for a in (w, mu, sigma))
+    S, P = w.shape
+    m = mu.shape[2]
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    L = np.stack([np.linalg.cholesky(sigma[k]) for k in range(P)])
+    out = np.empty((S, draws, m))
+    comp = np.empty((S, draws), dtype=np.int32)
+    d = np.arange(draws, dtype=np.uint64)
+    for s in range(S):
+        ctr = np.stack([d, np.full(draws, s, np.uint64), np.zeros(draws, np.uint64),
+                        np.zeros(draws, np.uint64)], axis=-1)
+        r0 = philox4x32_10(ctr, key)
+        u = _u01(r0[:, 0], r0[:, 1])
+        cdf = np.cumsum(w[s])
+        k = np.minimum((u[:, None] >= cdf[None, :]).sum(axis=1), P - 1)
+        comp[s] = k
+        z = np.empty((draws, m + 1))
+        for b in range((m + 1) // 2):
+            ctr[:, 2] = 1 + b
+            r = philox4x32_10(ctr, key)
+            u1, u2 = _u01(r[:, 0], r[:, 1]), _u01(r[:, 2], r[:, 3])
+            rad, ang = np.sqrt(-2.0 * np.log(u1)), 2.0 * np.pi * u2
+            z[:, 2 * b], z[:, 2 * b + 1] = rad * np.cos(ang), rad * np.sin(ang)
+        out[s] = mu[k, s, :] + np.einsum("dij,dj->di", L[k], z[:, :m])
+    return out, comp

@@ -214,6 +214,33 @@ def test_cached_factor_per_item_data_and_limits(ctx):
     ctx.set_spec(NgpSpec(0, 0, 0, 0, 1e-5))
 
 
+@pytest.mark.parametrize("P,S,m,draws", [(1, 1, 1, 7), (3, 2, 4, 33), (8, 5, 9, 200), (5, 3, 52, 40)])
+def test_device_mixture_sampler_follows_the_oracle_stream(ctx, P, S, m, draws):
+    """ngp_mixture_sample against the numpy restatement of the same Philox stream: same component
+    picks, same draws (the two Cholesky orders differ by rounding only)."""
+    rng = np.random.Generator(np.random.PCG64(P * 100 + m))
+    w = rng.dirichlet(np.ones(P), size=S)
+    mu = rng.standard_normal((P, S, m))
+    A = rng.standard_normal((P, m, m))
+    sigma = A @ A.transpose(0, 2, 1) / m + 0.1 * np.eye(m)
+    seed = 0x0123456789ABCDEF + m
+    out, comp, info = ctx.mixture_sample(w, mu, sigma, draws, seed)
+    ref, rcomp = oracle_np.mixture_sample(w, mu, sigma, draws, seed)
+    assert not info.any() and np.array_equal(comp, rcomp)
+    assert nerr(out, ref) < 1e-12
+    again, _, _ = ctx.mixture_sample(w, mu, sigma, draws, seed)
+    other, _, _ = ctx.mixture_sample(w, mu, sigma, draws, seed + 1)
+    assert np.array_equal(out, again) and not np.array_equal(out, other)
+
+
+def test_device_mixture_sampler_reports_a_bad_covariance(ctx):
+    sigma = np.stack([np.eye(3), np.array([[1.0, 2, 0], [2, 1, 0], [0, 0, 1]])])
+    _, _, info = ctx.mixture_sample(np.array([[0.5, 0.5]]), np.zeros((2, 1, 3)), sigma, 4, 1)
+    assert info[0] == 0 and info[1] == 2
+    with pytest.raises(_lib.NgpError):
+        ctx.mixture_sample(np.ones((1, 1)), np.zeros((1, 1, 200)), np.eye(200)[None], 1, 1)
+
+
 def test_noise_on_new_flag(ctx):
     w = make_workload("C1", n=90, P=2, D=1, d=1, m=4)
     a = ctx.predict_batch(w.programs, w.t, w.y, w.t_new, noise_on_new=True)[1]

@@ -73,7 +73,7 @@ def test_repeated_forecasts_reuse_the_resident_factor(eng):
     class NoCache:   # same device library, but every call factorises from scratch
         def __init__(self, inner):
             self.ctx = inner.ctx
-            for name in ("logml", "logml_grad", "predict", "nowcast"):
+            for name in ("logml", "logml_grad", "predict", "nowcast", "mixture_sample"):
                 setattr(self, name, getattr(inner, name))
 
     base, multi = mc.nowcast_fixture(eng)

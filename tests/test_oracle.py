@@ -137,3 +137,29 @@ def test_weights_normalize():
 ])
 def test_malformed_programs_rejected(bad):
     assert oracle_c.kernel_check(bad) != 0
+
+
+def test_philox_known_answers_and_mixture_moments():
+    """The sampler's stream is Philox4x32-10; the restatement is pinned by the published Random123
+    known-answer vectors, and its draws by the mixture's first two moments."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert [int(x) for x in oracle_np.philox4x32_10(ctr, key)] == want
+    rng = np.random.Generator(np.random.PCG64(1))
+    P, S, m, draws = 3, 2, 4, 60000
+    w = rng.dirichlet(np.ones(P), size=S)
+    mu = rng.standard_normal((P, S, m))
+    A = rng.standard_normal((P, m, m))
+    sigma = A @ A.transpose(0, 2, 1) + 0.5 * np.eye(m)
+    out, comp = oracle_np.mixture_sample(w, mu, sigma, draws, seed=0x1234567890ABCDEF)
+    for s in range(S):
+        freq = np.bincount(comp[s], minlength=P) / draws
+        assert np.abs(freq - w[s]).max() < 4 * np.sqrt(0.25 / draws)
+        mean = w[s] @ mu[:, s, :]
+        second = sum(w[s, k] * (sigma[k] + np.outer(mu[k, s], mu[k, s])) for k in range(P))
+        cov = second - np.outer(mean, mean)
+        assert np.abs(out[s].mean(axis=0) - mean).max() < 5 * np.sqrt(np.diag(cov).max() / draws)
+        assert np.abs(np.cov(out[s].T) - cov).max() < 0.08 * np.abs(cov).max()
