@@ -444,7 +444,7 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p0, int bc,
         // class 0: the LDS-DMA kernel of the fat steps (the dominant kernel, the roofline figure);
         // class 6: the direct-load kernel of the thin / full steps
         tm.run(fat ? 0 : 6, bc * fl, bc * by,
-               [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, ahead, s); });
+               [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, s); });
         if (ahead && jj > 0) {
             (void)hipEventRecord(ln.fork, s);
             (void)hipStreamWaitEvent(ln.side, ln.fork, 0);
@@ -885,7 +885,7 @@ ngp_status factor_run(ngp_factor *f, ngp_job *j, bool create) {
                 ChunkPtrs pj = p;
                 pj.dinv = f->dinv + (size_t)jj * mstep;
                 tm.run(6, P * nrows_aux * (double)NB * NB, P * 8.0 * 3.0 * nrows_aux * NB,
-                       [&] { launch_chol_col(g, pj, P, jj, COL_AUX, jj * NB, 0, s); });
+                       [&] { launch_chol_col(g, pj, P, jj, COL_AUX, jj * NB, s); });
                 tm.run(7, P * nrows_aux * 2.0 * NB * (double)(g.n0 - (jj + 1) * NB),
                        P * 8.0 * (g.n0 - (jj + 1) * NB) * (2.0 * nrows_aux + NB),
                        [&] { launch_aux_update(g, pj, P, jj, s); });

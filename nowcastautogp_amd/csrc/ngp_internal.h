@@ -101,7 +101,7 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
 void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int k0, hipStream_t s);
 enum { COL_FULL = 0, COL_FAT = 1, COL_THIN = 2, COL_AUX = 3 };
 void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mode, int k0,
-                     int ahead, hipStream_t s);
+                     hipStream_t s);
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,

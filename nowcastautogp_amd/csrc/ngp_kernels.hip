@@ -920,7 +920,6 @@ struct ColStep {
     int nmain;    // main row tiles below the diagonal (r = j+1 ...); 0: aux tiles only
     int ntiles;   // nmain + aux tiles
     int groups;   // workgroups per item
-    int ahead;    // unused (the diag-ahead tile has its own kernel)
     int dbg;      // timing ablations of the fat kernel (results wrong when != 0): 1 no restaging,
                   // 2 no barriers, 4 no epilogue, 8 no K-tile reads, 16 no M C' product, 32 no row
                   // stores; from the NGP_ABLATE environment variable only, never through the API
@@ -1894,14 +1893,13 @@ void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int k
 }
 
 void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mode, int k0,
-                     int ahead, hipStream_t s) {
+                     hipStream_t s) {
     ColStep st{};
     static const int dbg = getenv("NGP_ABLATE") ? atoi(getenv("NGP_ABLATE")) : 0;
     st.dbg = dbg;
     st.j = j;
     st.k0 = k0;
     st.nmain = (mode == COL_AUX) ? 0 : g.nb0 - 1 - j;
-    st.ahead = 0;
     st.ntiles = st.nmain + g.naux_pad / NB;
     if (st.ntiles <= 0) return;
     const int bpad = (Bc + 7) / 8 * 8;
@@ -1909,7 +1907,6 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
         st.groups = (st.ntiles + 1) / 2;
         hipLaunchKernelGGL(chol_col_glds_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p, Bc,
                            st);
-        (void)ahead;
     } else {
         st.groups = (st.ntiles + 3) / 4;
         hipLaunchKernelGGL(chol_col_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p,
