@@ -80,3 +80,67 @@ def test_context_fails_loudly_without_a_gpu(lib):
         pytest.skip("a GPU is present")
     with pytest.raises(_lib.NgpError):
         _lib.Context(0)
+
+
+def _py_check(ops, n_params):
+    """Independent statement of what a well-formed program is (include/ngp.h): opcodes 1..8 in
+    postfix order leaving exactly one value, parameter count equal to the sum of the leaves' and
+    ChangePoints' arities, sizes within NGP_MAX_OPS / NGP_MAX_PARAMS / NGP_MAX_STACK."""
+    arity = {1: 1, 2: 3, 3: 2, 4: 3, 5: 3, 6: 0, 7: 0, 8: 2}
+    if not 0 < len(ops) <= 64:
+        return False
+    depth = npar = 0
+    for op in ops:
+        if op not in arity:
+            return False
+        npar += arity[op]
+        if op >= 6:
+            if depth < 2:
+                return False
+            depth -= 1
+        else:
+            depth += 1
+            if depth > 16:
+                return False
+    return depth == 1 and npar == n_params and npar <= 96
+
+
+def test_kernel_check_fuzz(lib):
+    """Random byte strings, mutated valid programs and boundary sizes: the validator agrees with
+    the independent statement above and with the C oracle's, and nothing crashes."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    cfg = gp.GPConfig()
+    cases = []
+    for _ in range(400):                       # arbitrary opcode strings
+        k = int(rng.integers(1, 12))
+        ops = rng.integers(0, 11, size=k).tolist()
+        cases.append((ops, int(rng.integers(0, 12))))
+    for _ in range(400):                       # valid trees, then one mutation
+        ops, params = gp.to_program(gp.sample_tree(rng, cfg, depth_cap=5))
+        ops = ops.tolist()
+        npar = len(params)
+        cases.append((list(ops), npar))
+        mut = int(rng.integers(0, 4))
+        if mut == 0:
+            ops[int(rng.integers(0, len(ops)))] = int(rng.integers(0, 11))
+        elif mut == 1:
+            ops = ops[:-1]
+        elif mut == 2:
+            ops = ops + [int(rng.integers(1, 9))]
+        else:
+            npar += int(rng.integers(-2, 3))
+        if ops:
+            cases.append((ops, max(npar, 0)))
+    cases.append(([2] * 33 + [6] * 32, 99))    # 65 ops: too large
+    cases.append(([5, 5, 6] + [5, 6] * 30, 96))   # 63 ops, 96 params, depth 2: the largest accepted
+    cases.append(([5] * 32 + [6] * 31, 96))    # same tree written leaves-first: depth 32, refused
+    cases.append(([5] * 17 + [6] * 16, 51))    # caller-order depth 17: beyond NGP_MAX_STACK
+    n_ok = 0
+    for ops, npar in cases:
+        prog = (np.asarray(ops, dtype=np.int32), np.full(npar, 0.3), 0.1)
+        want = _py_check(ops, npar)
+        assert (_lib.kernel_check(prog) == 0) == want, (ops, npar)
+        assert (oracle_c.kernel_check(prog) == 0) == want, (ops, npar)
+        n_ok += want
+    assert _py_check([5, 5, 6] + [5, 6] * 30, 96) and not _py_check([5] * 32 + [6] * 31, 96)
+    assert 300 < n_ok < len(cases) - 300

@@ -474,3 +474,22 @@ def test_long_history_8192(ctx):
     lf, i0 = oracle_np.logml(w.programs[0], tt, np.concatenate([w.y, w.y_add[0]]))
     # (no SVD of an 8193 x 8193 matrix in the test: flat 1e-9 instead of the cond-aware bound)
     assert i0 == 0 and nerr(out["logml_full"][0, 0], lf) < 1e-9
+
+
+def test_plain_c_consumer_of_the_abi(ctx, tmp_path):
+    """include/ngp.h is usable as written from plain C (what the Julia ccall shim relies on):
+    tests/c/abi_consumer.c is compiled with gcc, linked against libngp.so and the C oracle, and
+    runs every batched entry point, the resident factor, the sampler and the error returns."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    oracle_c.build()
+    exe = str(tmp_path / "abi_consumer")
+    libdir, odir = os.path.join(root, "nowcastautogp_amd"), os.path.join(root, "oracle")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-o", exe,
+                           os.path.join(root, "tests", "c", "abi_consumer.c"), "-L" + libdir,
+                           "-L" + odir, "-lngp", "-lngp_oracle", "-lm",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath," + odir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
