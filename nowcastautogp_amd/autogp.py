@@ -397,59 +397,66 @@ def _latents(model: GPModel):
 
 def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
     """One HMC transition per particle on the N(0,1) latents z of (parameters, noise):
-    U(z) = -log p(y | theta(z)) + |z|^2 / 2, gradient through the engine's logml gradient."""
+    U(z) = -log p(y | theta(z)) + |z|^2 / 2, gradient through the engine's logml gradient.
+    All particles move together: the latents live in one flat vector (``sl[k]`` is particle k's
+    slice), every leapfrog stage is one engine call and a handful of numpy operations."""
     rng, prior = model.rng, model.config.prior
     fixed_noise = model.config.noise is not None
     P = len(model.particles)
     z0, kinds = _latents(model)
     ops = [gp.to_program(p.tree)[0] for p in model.particles]
+    sizes = np.array([z.size for z in z0])
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    sl = [slice(int(off[k]), int(off[k + 1])) for k in range(P)]
+    seg = np.repeat(np.arange(P), sizes)                     # particle of every latent
+    codes = np.array([gp.KIND_CODES[k_] for kd in kinds for k_ in kd])
+    last = off[1:] - 1                                       # the noise latent of every particle
+    positive = (codes == gp.KIND_CODES["wildcard"]) | (codes == gp.KIND_CODES["period"])
+    is_gamma, is_unit = codes == gp.KIND_CODES["gamma"], codes == gp.KIND_CODES["unit"]
 
-    def potential(zs):
-        progs, dths = [], []
-        for z, kd, op in zip(zs, kinds, ops):
-            th, dth = gp.transform(np.nan_to_num(z, nan=0.0, posinf=50.0, neginf=-50.0), kd, prior)
-            # degenerate parameters (a diverged trajectory) would only produce a non-PD matrix
-            # and a rejection; keep them inside what the kernels accept
-            th = np.clip(th, -1e6, 1e6)
-            for i_, k_ in enumerate(kd):
-                if k_ in ("wildcard", "period"):
-                    th[i_] = max(th[i_], 1e-12)
-                elif k_ == "gamma":
-                    th[i_] = min(max(th[i_], 1e-9), 2.0 - 1e-9)
-                elif k_ == "unit":
-                    th[i_] = min(max(th[i_], 1e-9), 1.0 - 1e-9)
-            progs.append((op, th[:-1], float(th[-1])))
-            dths.append(dth)
+    def sums(v):                                             # per-particle sums of a flat vector
+        return np.bincount(seg, weights=v, minlength=P)
+
+    def potential(z):
+        th, dth = gp.transform_flat(np.nan_to_num(z, nan=0.0, posinf=50.0, neginf=-50.0), codes,
+                                    prior)
+        # degenerate parameters (a diverged trajectory) would only produce a non-PD matrix and a
+        # rejection; keep them inside what the kernels accept
+        th = np.clip(th, -1e6, 1e6)
+        th[positive] = np.maximum(th[positive], 1e-12)
+        th[is_gamma] = np.clip(th[is_gamma], 1e-9, 2.0 - 1e-9)
+        th[is_unit] = np.clip(th[is_unit], 1e-9, 1.0 - 1e-9)
+        progs = [(ops[k], th[sl[k]][:-1], float(th[last[k]])) for k in range(P)]
         lm, grads, info = model._eng().logml_grad(progs, t, y)
-        U, dU = np.empty(P), []
-        for k in range(P):
-            ok = info[k] == 0 and np.isfinite(lm[k]) and np.all(np.isfinite(grads[k]))
-            U[k] = (-lm[k] + 0.5 * zs[k] @ zs[k]) if ok else np.inf
-            g = -grads[k] * dths[k] + zs[k] if ok else np.zeros_like(zs[k])
-            if fixed_noise:
-                g[-1] = 0.0
-            dU.append(g)
+        g = np.concatenate(grads)
+        with np.errstate(invalid="ignore", over="ignore"):
+            ok = (np.asarray(info) == 0) & np.isfinite(lm) & (sums(~np.isfinite(g)) == 0)
+            U = np.where(ok, -np.asarray(lm) + 0.5 * sums(z * z), np.inf)
+            dU = np.where(ok[seg], -g * dth + z, 0.0)
+        if fixed_noise:
+            dU[last] = 0.0
         return U, dU, lm
 
+    z0 = np.concatenate(z0)
     U0, dU, _ = potential(z0)
-    mom = [rng.standard_normal(z.size) for z in z0]
+    mom = rng.standard_normal(z0.size)
     if fixed_noise:
-        for m_ in mom:
-            m_[-1] = 0.0
-    H0 = U0 + np.array([0.5 * m_ @ m_ for m_ in mom])
-    z = [a.copy() for a in z0]
-    pm = [m_ - 0.5 * eps * g for m_, g in zip(mom, dU)]
-    lm1 = None
+        mom[last] = 0.0
+    H0 = U0 + 0.5 * sums(mom * mom)
+    z = z0.copy()
+    pm = mom - 0.5 * eps * dU
+    lm1 = U1 = None
     for step in range(n_leapfrog):
-        z = [a + eps * b for a, b in zip(z, pm)]
+        z = z + eps * pm
         U1, dU, lm1 = potential(z)
-        scale = eps if step < n_leapfrog - 1 else 0.5 * eps
-        pm = [m_ - scale * g for m_, g in zip(pm, dU)]
-    H1 = U1 + np.array([0.5 * m_ @ m_ for m_ in pm])
+        pm = pm - (eps if step < n_leapfrog - 1 else 0.5 * eps) * dU
+    with np.errstate(invalid="ignore", over="ignore"):
+        H1 = U1 + 0.5 * sums(pm * pm)
+    th_new, _ = gp.transform_flat(z, codes, prior)
     acc = 0
     for k in range(P):
         if np.isfinite(H1[k]) and math.log(rng.random()) < H0[k] - H1[k]:
-            th, _ = gp.transform(z[k], kinds[k], prior)
+            th = th_new[sl[k]]
             model.particles[k].tree = gp.from_program(ops[k], th[:-1])
             model.particles[k].noise = float(th[-1])
             model._logml[k] = float(lm1[k])

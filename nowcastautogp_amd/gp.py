@@ -248,6 +248,42 @@ def transform(z: np.ndarray, kinds: Sequence[str], prior) -> Tuple[np.ndarray, n
     return th, dth
 
 
+KIND_CODES = {"real": 0, "unit": 1, "gamma": 2, "period": 3, "wildcard": 4}
+
+
+def transform_flat(z: np.ndarray, codes: np.ndarray, prior) -> Tuple[np.ndarray, np.ndarray]:
+    """``transform`` for many particles at once: ``z`` and the integer kind ``codes``
+    (``KIND_CODES``) are the concatenation over particles.  Same maps, same clamping of the
+    argument of exp / sigmoid, evaluated with numpy instead of a Python loop per element."""
+    z = np.asarray(z, dtype=np.float64)
+    th = np.empty_like(z)
+    dth = np.empty_like(z)
+
+    def sigmoid(x):
+        x = np.clip(x, -700.0, 700.0)
+        e = np.exp(-np.abs(x))
+        return np.where(x >= 0, 1.0 / (1.0 + e), e / (1.0 + e))
+
+    m = codes == 0
+    th[m], dth[m] = z[m], 1.0
+    m = codes == 1
+    if m.any():
+        sg = sigmoid(z[m])
+        th[m], dth[m] = sg, sg * (1 - sg)
+    m = codes == 2
+    if m.any():
+        pr = prior["gamma"]
+        sg = sigmoid(pr["mu"] + pr["sigma"] * z[m])
+        th[m], dth[m] = 2.0 * sg, 2.0 * sg * (1 - sg) * pr["sigma"]
+    for code, name in ((3, "period"), (4, "wildcard")):
+        m = codes == code
+        if m.any():
+            pr = prior[name]
+            v = np.exp(np.clip(pr["mu"] + pr["sigma"] * z[m], -300.0, 300.0))
+            th[m], dth[m] = v, v * pr["sigma"]
+    return th, dth
+
+
 def untransform(theta: np.ndarray, kinds: Sequence[str], prior) -> np.ndarray:
     theta = np.asarray(theta, dtype=np.float64)
     z = np.empty_like(theta)

@@ -131,3 +131,19 @@ def test_divergent_hmc_trajectory_is_rejected_not_raised(eng):
     assert np.allclose(model._logml, fresh, rtol=1e-9)
     for p, b in zip(model.particles, before):
         assert np.isfinite(p.program()[1]).all() and p.noise > 0
+
+
+def test_transform_flat_equals_the_per_particle_transform():
+    rng = np.random.Generator(np.random.PCG64(11))
+    cfg = gp.GPConfig()
+    kinds, zs = [], []
+    for _ in range(40):
+        ops, _ = gp.to_program(gp.sample_tree(rng, cfg, depth_cap=5))
+        kd = gp.param_kinds(ops) + [gp.NOISE_KIND]
+        kinds.append(kd)
+        zs.append(rng.standard_normal(len(kd)) * rng.choice([0.3, 3.0, 400.0]))
+    codes = np.array([gp.KIND_CODES[k] for kd in kinds for k in kd])
+    th, dth = gp.transform_flat(np.concatenate(zs), codes, cfg.prior)
+    ref = [gp.transform(z, kd, cfg.prior) for z, kd in zip(zs, kinds)]
+    assert np.allclose(th, np.concatenate([r[0] for r in ref]), rtol=1e-14, atol=0)
+    assert np.allclose(dth, np.concatenate([r[1] for r in ref]), rtol=1e-13, atol=1e-300)
