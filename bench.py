@@ -130,10 +130,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the GP hot path has no CPU fallback")
+    # Rehearsal of the N > 1 control flow on a one-GPU box (NGP_BENCH_REHEARSE=1): all ranks share
+    # device 0 and the collectives go over gloo.  Never used for a reported number.
+    rehearse = os.environ.get("NGP_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -182,7 +190,7 @@ def main():
     ctx.profile_enable(False)
     prof = ctx.profile_get()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     bad = int((out["info"] != 0).sum())
