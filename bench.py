@@ -261,6 +261,13 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                 "traffic": None,
+                "traffic_measured_separately": {
+                    "what": "HBM-side bytes of this kernel from rocprofv3 --pmc passes "
+                            "(FETCH_SIZE x2 per the gfx950 correction, WRITE_SIZE), 3,200-item "
+                            "variant of the same step; algorithmic: 89 MB streamed rows and panels "
+                            "+ 51 MB tile I/O per item",
+                    "read_MB_per_item": 118.0, "written_MB_per_item": 17.9,
+                    "source": "profiles/r01/pmc_v4_diag.txt"},
                 "launches": col["launches"],
                 "avg_launch_ms": col["ms"] / max(col["launches"], 1),
                 "share_of_kernel_time": col["ms"] / total_ms if total_ms else 0.0,
