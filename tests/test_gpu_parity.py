@@ -493,3 +493,66 @@ def test_plain_c_consumer_of_the_abi(ctx, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
+
+
+def test_randomised_differential_against_the_oracle(ctx):
+    """Sixty random problems — series length, tree, time grid (lattice / jittered / with gaps),
+    number of appended points, scenarios, horizon and recalled-formula flags all drawn at random —
+    through the one-call path and, every third one, the gradient: every output against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(20260612))
+    cfg = gp.GPConfig()
+    worst = 0.0
+    for case in range(60):
+        n = int(rng.choice([1, 2, 17, 63, 64, 65, 100, 129, 200, 257, 300]))
+        d, m, D = int(rng.integers(0, 4)), int(rng.integers(0, 12)), int(rng.integers(1, 5))
+        grid = case % 3
+        if grid == 0:
+            t_all = np.arange(n + d + m) / max(n - 1, 1)
+        elif grid == 1:
+            t_all = np.sort(rng.uniform(0, 1.3, n + d + m))
+        else:                                  # weekly dates with missing weeks
+            keep = np.sort(rng.choice(3 * (n + d + m), size=n + d + m, replace=False))
+            t_all = keep / max(keep[max(n - 1, 0)], 1)
+        t, t_add, t_new = t_all[:n], t_all[n:n + d], t_all[n + d:]
+        spec = NgpSpec(int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2)), 0,
+                       float(rng.choice([1e-5, 1e-3])))
+        ctx.set_spec(spec)
+        sp = {"se_form": spec.se_form, "periodic_form": spec.periodic_form, "cp_form": spec.cp_form,
+              "jitter": spec.jitter}
+        progs = []
+        for _ in range(3):
+            ops, params = gp.to_program(gp.sample_tree(rng, cfg, depth_cap=int(rng.integers(1, 6))))
+            progs.append((ops, params, float(10 ** rng.uniform(-3, -0.5))))
+        y = rng.standard_normal(n)
+        y_add = rng.standard_normal((D, d))
+        got = ctx.nowcast_batch(progs, t, y, t_add, y_add, t_new)
+        for p, prog in enumerate(progs):
+            tt = np.concatenate([t, t_add])
+            cond = np.linalg.cond(oracle_np.cov(prog, tt, tt, True, sp))
+            if not np.isfinite(cond) or cond > 1e9:
+                continue
+            if m:
+                lb, lf, mu, sg, oi = oracle_np.nowcast(prog, t, y, t_add, y_add, t_new, True, sp)
+            else:
+                lb = oracle_np.logml(prog, t, y, sp)[0]
+                lf = [oracle_np.logml(prog, tt, np.concatenate([y, y_add[s]]), sp)[0] for s in range(D)]
+            assert got["info"][p] == 0, (case, p)
+            e1 = nerr(got["logml_base"][p], lb) / tol(TOL_LOGML, cond)
+            e2 = nerr(got["logml_full"][p], lf) / tol(TOL_LOGML, cond)
+            e3 = e4 = 0.0
+            if m:
+                e3 = nerr(got["mu"][p], mu) / tol(TOL_PRED, cond)
+                e4 = nerr(got["sigma"][p], sg) / tol(TOL_PRED, cond)
+            worst = max(worst, e1, e2, e3, e4)
+            assert max(e1, e2, e3, e4) < 1.0, (case, p, n, d, m, D, grid, e1, e2, e3, e4)
+        if case % 3 == 0 and n >= 2:
+            lm, grads, info = ctx.logml_grad_batch(progs, t, y)
+            for p, prog in enumerate(progs):
+                cond = np.linalg.cond(oracle_np.cov(prog, t, t, True, sp))
+                if not np.isfinite(cond) or cond > 1e8:
+                    continue
+                rlm, rg, _ = oracle_c.logml_grad(prog, t, y, spec)
+                assert nerr(lm[p], rlm) < tol(TOL_LOGML, cond), (case, p)
+                assert nerr(grads[p], rg) < tol(1e-7, cond), (case, p, n)
+    ctx.set_spec(NgpSpec(0, 0, 0, 0, 1e-5))
+    assert worst > 0.0
