@@ -1074,13 +1074,14 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     if (!c || !kernels || !t || !y || !grad || B <= 0 || n <= 0) return NGP_ERR_ARG;
     std::vector<DevProgram> hp((size_t)B);
     std::vector<std::vector<int>> perm((size_t)B);
-    int maxstat = 0, maxcp = 0;
+    int maxstat = 0, maxcp = 0, maxops = 0;
     for (int i = 0; i < B; ++i) {
         int ns = 0, nc = 0;
         ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], &perm[(size_t)i], &ns, &nc);
         if (st) return st;
         maxstat = std::max(maxstat, ns);
         maxcp = std::max(maxcp, nc);
+        maxops = std::max(maxops, (int)kernels[i].n_ops);
     }
     // Geometry: the matrix is padded to a multiple of 64 with identity rows/cols (log 1 = 0, a
     // zero in y), and the aux block is [I ; y'] so that the factorisation leaves W = [L^-T ; z'].
@@ -1090,6 +1091,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     g.nb0 = g.n0 / NB;
     g.n_real = n;
     g.aux_identity = 1;
+    g.maxops = maxops;
     g.naux = g.n0 + 1;
     g.naux_pad = g.n0 + NB;
     g.D = 1;

@@ -56,7 +56,7 @@ struct JobGeom {
     int32_t maxcp;     // ChangePoint sigmoid slots per item
     int32_t n_real;    // main-block points that are data; rows/cols beyond are identity padding
     int32_t aux_identity;  // 1: aux rows are [I_n0 ; y'] (gradient path: W = L^-T)
-    int32_t pad0;
+    int32_t maxops;    // longest program of the batch (gradient jobs: picks the contraction kernel)
     double  h;         // lattice step
     int64_t ld;        // row stride of the factor storage (= n0)
     int64_t item_stride;  // elements per item in the factor storage

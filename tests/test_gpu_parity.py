@@ -384,6 +384,13 @@ def test_gradient_random_trees_and_child_reordering(ctx, n, lattice):
     for i in range(5):
         chain = gp.ChangePoint(gp.Periodic(0.9, 0.21 + 0.03 * i, 0.4), chain, 0.3 + 0.1 * i, 0.07)
     progs.append(gp.to_program(chain) + (0.02,))
+    if n in (200, 400):   # a program longer than the LDS-resident contraction holds (16 operators):
+        long = gp.Linear(0.2, 0.1, 0.2)   # the whole batch then takes the private-array kernel
+        for i in range(9):
+            long = gp.Plus(gp.Times(gp.SquaredExponential(0.3 + 0.05 * i, 0.5),
+                                    gp.GammaExponential(0.4, 1.1 + 0.05 * i, 0.6)), long)
+        assert len(gp.to_program(long)[0]) > 16
+        progs.append(gp.to_program(long) + (0.03,))
     t = np.arange(n) / (n - 1) if lattice else np.sort(rng.uniform(0, 1, n))
     Y = rng.standard_normal((len(progs), n))
     lm, grads, info = ctx.logml_grad_batch(progs, t, Y)
