@@ -842,11 +842,15 @@ ngp_status factor_run(ngp_factor *f, ngp_job *j, bool create) {
     EventTimer tm(c->profiling, s);
     const int P = f->P;
     void *tab = nullptr, *sig = nullptr;
+    struct Scratch {   // the tables go back to the allocator on every exit path
+        ngp_ctx *c; void *&a, *&b;
+        ~Scratch() { c->release(a); c->release(b); }
+    } scratch{c, tab, sig};
     if (g.n0 > 0) {
         if (g.lattice) {
             ngp_status st = c->alloc(&tab, sizeof(double) * (size_t)g.maxstat * g.R * P);
             if (!st) st = c->alloc(&sig, sizeof(double) * (size_t)g.maxcp * g.npts * P);
-            if (st) { c->release(tab); c->release(sig); return st; }
+            if (st) return st;
         }
         ChunkPtrs p{};
         p.L = f->L;
@@ -915,8 +919,6 @@ ngp_status factor_run(ngp_factor *f, ngp_job *j, bool create) {
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipGetLastError();
     tm.resolve(c->prof);
-    c->release(tab);
-    c->release(sig);
     if (err != hipSuccess) return (ngp_status)err;
     j->ran = true;
     return NGP_OK;
