@@ -1238,9 +1238,14 @@ __global__ __launch_bounds__(256) void gram_kernel(JobGeom g, const double *L, d
 //   logml_full = -1/2 (G_YY + |z_A|^2) - (logdet0 + sum log diag L_A) - (n+d)/2 log 2pi
 //   mu = G_TY + V_A z_A ;  logml_base = same with the first `tail` appended rows only
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevSpec sp) {
+// The working set (L_A, V_A, log diag) lives in dynamic LDS when it fits (lds_work != 0; the usual
+// case: a ragged tail of < 64 points plus a few appended ones) — the pivot loop of the da x da
+// factorisation is a chain of dependent accesses, 114 us from global memory against ~20 from LDS
+// at da = 22 — and in the per-item global work buffer otherwise.
+__global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevSpec sp, int lds_work) {
     __shared__ DevProgram P;
     __shared__ int bad;
+    extern __shared__ double epi_dyn[];
     const int item = blockIdx.x, tid = threadIdx.x;
     load_program(&P, p.progs + item);
     if (tid == 0) bad = 0;
@@ -1249,7 +1254,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
     const double nz = P.noise + sp.jitter;
     const double *G = p.G + (long)item * na * na;
     const double *ta = p.taux, *tt = p.taux + da;
-    double *work = p.work + (long)item * p.work_stride;
+    double *work = lds_work ? epi_dyn : p.work + (long)item * p.work_stride;
     double *LA = work;                  // [da x da]
     double *VA = LA + (long)da * da;    // [m x da]
     double *ldA = VA + (long)m * da;    // [da] log diag L_A
@@ -1264,23 +1269,24 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
         LA[e] = v;
     }
     __syncthreads();
-    for (int k = 0; k < da; ++k) {  // in-place right-looking Cholesky of S_AA
+    for (int k = 0; k < da; ++k) {  // in-place right-looking Cholesky of S_AA (one wave: row per thread)
         const double akk = LA[k * da + k];
         const double dk = sqrt(akk);
         __syncthreads();
         if (tid == 0) {
             if (!(akk > 0.0) && bad == 0) bad = k + 1;
             LA[k * da + k] = dk;
-            ldA[k] = log(dk);
         }
         for (int i = k + 1 + tid; i < da; i += 64) LA[i * da + k] /= dk;
         __syncthreads();
-        for (int e = tid; e < (da - k - 1) * (da - k - 1); e += 64) {
-            const int i = k + 1 + e / (da - k - 1), jj = k + 1 + e % (da - k - 1);
-            if (jj <= i) LA[i * da + jj] -= LA[i * da + k] * LA[jj * da + k];
+        for (int i = k + 1 + tid; i < da; i += 64) {
+            const double lik = LA[i * da + k];
+            for (int jj = k + 1; jj <= i; ++jj) LA[i * da + jj] -= lik * LA[jj * da + k];
         }
         __syncthreads();
     }
+    for (int a = tid; a < da; a += 64) ldA[a] = log(LA[a * da + a]);
+    __syncthreads();
     // V_A: one forecast row per thread, forward substitution along the appended points
     for (int i = tid; i < m; i += 64) {
         for (int a = 0; a < da; ++a) {
@@ -1306,6 +1312,43 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
     const double ld0 = p.logdet[item];
     const double LOG2PI = 1.8378770664093454836;
     const double *ya_base = p.ya + (g.y_shared ? 0 : (long)item * g.D * da);
+    if (g.D <= 8) {
+        // few scenarios (a logml / predict call): the wave solves them one after the other, every
+        // row's dot product spread over the lanes, instead of one long serial loop on one lane
+        for (int s = 0; s < g.D; ++s) {
+            const double *ya = ya_base + (long)s * da;
+            double *z = p.zbuf + ((long)item * g.D + s) * da;
+            double quad = 0.0, quad_tail = 0.0, ldsum = 0.0, ld_tail = 0.0;
+            for (int a = 0; a < da; ++a) {
+                double part = 0.0;
+                for (int pp = tid; pp < a; pp += 64) part += LA[a * da + pp] * z[pp];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+                const double e = (ya[a] - (g.n0 ? G[a * na + Y] : 0.0) - part) / LA[a * da + a];
+                if (tid == 0) z[a] = e;
+                __syncthreads();
+                quad += e * e;
+                ldsum += ldA[a];
+                if (a < g.tail) { quad_tail += e * e; ld_tail += ldA[a]; }
+            }
+            const int nfull = g.n0 + da;
+            if (tid == 0) {
+                p.logml_full[(long)item * g.D + s] =
+                    -0.5 * (q0 + quad) - (ld0 + ldsum) - 0.5 * nfull * LOG2PI;
+                if (s == 0)
+                    p.logml_base[item] =
+                        -0.5 * (q0 + quad_tail) - (ld0 + ld_tail) - 0.5 * (g.n0 + g.tail) * LOG2PI;
+            }
+            if (p.mu) {
+                double *mu = p.mu + ((long)item * g.D + s) * m;
+                for (int i = tid; i < m; i += 64) {
+                    double v = g.n0 ? G[(da + i) * na + Y] : 0.0;
+                    for (int a = 0; a < da; ++a) v += VA[i * da + a] * z[a];
+                    mu[i] = v;
+                }
+            }
+        }
+    } else {
     for (int s = tid; s < g.D; s += 64) {
         const double *ya = ya_base + (long)s * da;
         double *z = p.zbuf + ((long)item * g.D + s) * da;
@@ -1332,6 +1375,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
                 mu[i] = v;
             }
         }
+    }
     }
     if (tid == 0 && bad && p.info[item] == 0) p.info[item] = g.n0 + bad;
 }
@@ -1988,7 +2032,10 @@ void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream
 }
 
 void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipStream_t s) {
-    hipLaunchKernelGGL(epilogue_kernel, dim3(g.B), dim3(64), 0, s, g, p, sp);
+    const size_t bytes = 8 * ((size_t)g.da * g.da + (size_t)g.m * g.da + (size_t)g.da);
+    const int lds_work = bytes > 0 && bytes <= 60 * 1024;
+    hipLaunchKernelGGL(epilogue_kernel, dim3(g.B), dim3(64), lds_work ? bytes : 0, s, g, p, sp,
+                       lds_work);
 }
 
 void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2, int n2,

@@ -8,7 +8,7 @@ from nowcastautogp_amd import _lib
 from nowcastautogp_amd.synthetic import make_workload
 
 ctx = _lib.Context(0)
-if len(sys.argv) > 2:          # e.g. "grad 2048": only that call, for a kernel trace
+if len(sys.argv) > 2:          # e.g. "logml_grad 2048": only that call, for a kernel trace
     w = make_workload("C3", n=int(sys.argv[2]), P=64, D=4)
     for _ in range(5):
         getattr(ctx, sys.argv[1] + "_batch")(w.programs, w.t, w.y)
