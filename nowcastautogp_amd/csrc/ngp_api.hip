@@ -1155,7 +1155,9 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
                        (st = dalloc(&d_dtab, 3 * tab_bytes * (size_t)Bc)))) ||
         (st = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||
         (st = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) || (st = dalloc(&d_quad, 8 * (size_t)Bc)) ||
-        (st = dalloc(&d_part, 8 * (size_t)Bc * ntri * GP)) ||
+        // a chunk that is cut finer (split 2 or 4) writes at most 4096 partial rows; a coarse one Bc ntri
+        (st = dalloc(&d_part, 8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc),
+                                                   4096) * GP)) ||
         (st = dalloc(&d_grad, 8 * (size_t)B * GP)) || (st = dalloc(&d_logml, 8 * (size_t)B))) {
         freeall();
         return st;

@@ -109,6 +109,10 @@ void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *a
 void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
                           const double *alpha, const double *quad, double *partials, double *grad,
                           double *logml, int Bc, const DevSpec &sp, hipStream_t s);
+// workgroups per 64x64 tile of the gradient contraction: small launches are cut finer
+inline int grad_contract_split(long ntri, long Bc) {
+    return ntri * Bc <= 1024 ? 4 : (ntri * Bc <= 2048 ? 2 : 1);
+}
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s);
 void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipStream_t s);
 void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2,

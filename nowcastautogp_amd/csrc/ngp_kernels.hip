@@ -1597,10 +1597,15 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
                                                                     const double *Kinv,
                                                                     const double *alpha,
                                                                     double *partials, int ntri,
-                                                                    DevSpec sp) {
+                                                                    int split, DevSpec sp) {
     __shared__ DevProgram P;
     __shared__ double red[4][NGP_MAX_PARAMS + 1];
-    const int item = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    // split: workgroups per 64x64 tile (1, 2 or 4).  A thread walks 16 / split rows; a small
+    // launch (few items, short series) is latency-bound on that walk, so it is cut into more,
+    // shorter workgroups (158 -> 60 us for 64 particles at n = 150).
+    const int item = blockIdx.y, tile = blockIdx.x / split, sub = blockIdx.x % split;
+    const int tid = threadIdx.x;
+    const int nrows = 16 / split;
     load_program(&P, p.progs + item);
     __syncthreads();
     // per-operator constants of the derivative formulas, once per workgroup: the element loop
@@ -1647,8 +1652,8 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
     if (col < g.n_real) {
         const double t2 = p.t0[col], ac = al[col];
         const int q2 = p.qpts[col];
-        for (int rr = 0; rr < 16; ++rr) {
-            const int row = r * NB + ty * 16 + rr;
+        for (int rr = 0; rr < nrows; ++rr) {
+            const int row = r * NB + ty * 16 + sub * nrows + rr;
             if (row >= g.n_real || col > row) continue;
             double w = al[row] * ac - Ki[(long)row * g.n0 + col];
             if (row == col) w *= 0.5;
@@ -1749,7 +1754,7 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
     }
     __syncthreads();
     if (tid <= np)
-        partials[((long)item * ntri + tile) * (NGP_MAX_PARAMS + 1) + tid] =
+        partials[((long)item * ntri * split + blockIdx.x) * (NGP_MAX_PARAMS + 1) + tid] =
             red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
@@ -2011,19 +2016,22 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
                           const double *alpha, const double *quad, double *partials, double *grad,
                           double *logml, int Bc, const DevSpec &sp, hipStream_t s) {
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
+    int nparts = ntri;
     if (g.lattice && p.dtab) {
+        const int split = grad_contract_split(ntri, Bc);
+        nparts = ntri * split;
         if (g.maxops <= LDSV_OPS)
-            hipLaunchKernelGGL(grad_contract_lattice_kernel<true>, dim3(ntri, Bc), dim3(256), 0, s, g,
-                               p, Kinv, alpha, partials, ntri, sp);
+            hipLaunchKernelGGL(grad_contract_lattice_kernel<true>, dim3(ntri * split, Bc), dim3(256),
+                               0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
         else
-            hipLaunchKernelGGL(grad_contract_lattice_kernel<false>, dim3(ntri, Bc), dim3(256), 0, s,
-                               g, p, Kinv, alpha, partials, ntri, sp);
+            hipLaunchKernelGGL(grad_contract_lattice_kernel<false>, dim3(ntri * split, Bc), dim3(256),
+                               0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
     } else {
         hipLaunchKernelGGL(grad_contract_kernel, dim3(ntri, Bc), dim3(256), 0, s, g, p.progs, p.t0,
                            Kinv, alpha, partials, ntri, sp);
     }
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(Bc), dim3(128), 0, s, g, p.progs, partials, quad,
-                       p.logdet, grad, logml, ntri);
+                       p.logdet, grad, logml, nparts);
 }
 
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s) {
