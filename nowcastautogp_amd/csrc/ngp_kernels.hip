@@ -396,13 +396,16 @@ __device__ __forceinline__ double keval_lattice(const DevProgram &P, const doubl
     return s0;
 }
 
+// split: workgroups per tile (1, 2, 4) — small launches are latency-bound on the 8 rows a thread
+// walks, so they are cut into more, shorter workgroups (as in the gradient contraction)
 __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs p, int ntri,
-                                                           int tile_off, DevSpec sp) {
+                                                           int tile_off, int split, DevSpec sp) {
     __shared__ DevProgram P;
     const int item = blockIdx.y;
     load_program(&P, p.progs + item);
     __syncthreads();
-    const int tile = blockIdx.x + tile_off;
+    const int tile = blockIdx.x / split + tile_off, sub = blockIdx.x % split;
+    const int nrows = 8 / split;
     int r, c;
     bool aux = false;
     if (tile < ntri) {
@@ -427,8 +430,8 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
     const double *sig = p.sig + (long)item * g.maxcp * g.npts;
     const int naux_t = g.da + g.m;
     const double *y0 = p.y0 + (g.y_shared ? 0 : (long)item * g.n0);
-    for (int rr = 0; rr < 8; ++rr) {
-        const int lr = ty * 8 + rr;
+    for (int rr = 0; rr < nrows; ++rr) {
+        const int lr = ty * 8 + sub * nrows + rr;
         f64x2 v;
         long row;
         if (!aux) {
@@ -1960,9 +1963,12 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
     const int ntiles = ntri + (g.naux_pad / NB) * g.nb0;
     const int off = aux_only ? ntri : 0;
-    if (g.lattice)
-        hipLaunchKernelGGL(fill_lattice_kernel, dim3(ntiles - off, Bc), dim3(256), 0, s, g, p, ntri,
-                           off, sp);
+    if (g.lattice) {
+        const long nwg = (long)(ntiles - off) * Bc;
+        const int split = nwg <= 1024 ? 4 : (nwg <= 2048 ? 2 : 1);
+        hipLaunchKernelGGL(fill_lattice_kernel, dim3((ntiles - off) * split, Bc), dim3(256), 0, s, g,
+                           p, ntri, off, split, sp);
+    }
     else
         hipLaunchKernelGGL(fill_kernel, dim3(ntiles - off, Bc), dim3(256), 0, s, g, p, ntri, off, sp);
 }
