@@ -608,6 +608,7 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
     void *Lbuf[2] = {nullptr, nullptr}, *dinv[2] = {nullptr, nullptr};
     void *tab[2] = {nullptr, nullptr}, *sig[2] = {nullptr, nullptr};
+    bool single_chunk = false;
     auto release_all = [&] {
         for (int l = 0; l < 2; ++l) {
             c->release(Lbuf[l]); c->release(dinv[l]); c->release(tab[l]); c->release(sig[l]);
@@ -626,6 +627,7 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
         static const int lanes_env = getenv("NGP_LANES") ? atoi(getenv("NGP_LANES")) : 1;
         const int nl = (lanes_env >= 2 && g.B >= 4096) ? 2 : 1;
         if (nl == 2) Bc = std::max(1, std::min(Bc / 2, (g.B + 1) / 2));
+        single_chunk = Bc >= g.B;
         const size_t l_bytes = (size_t)g.item_stride * sizeof(double);
         ngp_status st = NGP_OK;
         for (int l = 0; l < nl && !st; ++l) {
@@ -688,6 +690,11 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     e.mu = j->mu;
     e.sigma = j->sigma;
     e.work_stride = j->work_stride;
+    if (g.lattice && single_chunk) {   // the tables of the only chunk are still in place
+        e.tab = (const double *)tab[0];
+        e.sig = (const double *)sig[0];
+        e.qpts = j->qpts;
+    }
     tm.run(3, 0.0, 0.0, [&] { launch_epilogue(g, e, sp, s); });
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipGetLastError();
@@ -915,6 +922,11 @@ ngp_status factor_run(ngp_factor *f, ngp_job *j, bool create) {
     e.mu = j->mu;
     e.sigma = j->sigma;
     e.work_stride = j->work_stride;
+    if (g.lattice && g.n0 > 0) {
+        e.tab = (const double *)tab;
+        e.sig = (const double *)sig;
+        e.qpts = j->qpts;
+    }
     tm.run(3, 0.0, 0.0, [&] { launch_epilogue(g, e, sp, s); });
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipGetLastError();

@@ -92,6 +92,10 @@ struct EpiPtrs {
     double       *mu;         // [B][D][m]
     double       *sigma;      // [B][m][m]
     int64_t       work_stride;
+    // lattice tables of the aux points when they are still resident (single-chunk jobs), else null:
+    // the small Schur blocks are then lookups instead of fp64 transcendental evaluations
+    const double *tab, *sig;  // [B][maxstat][R], [B][maxcp][npts]
+    const int32_t *qpts;      // [npts]
 };
 
 // ---- launchers implemented in ngp_kernels.hip ------------------------------------------

@@ -1216,6 +1216,25 @@ __global__ __launch_bounds__(256) void gram_kernel(JobGeom g, const double *L, d
     const double *W = L + (long)item * g.item_stride + (long)g.n0 * g.ld;
     double *Go = G + (long)item * g.naux * g.naux;
     const int npairs = g.naux * (g.naux + 1) / 2;
+    if (g.n0 <= 512) {
+        // short rows: one pair per thread, a serial dot product over at most 512 elements that sit
+        // in L1 (the wave-per-pair form below spends its time on index arithmetic and shuffles: 46 us
+        // for 276 pairs at n0 = 128)
+        for (int e = threadIdx.x; e < g.naux * g.naux; e += 256) {
+            const int a = e / g.naux, b = e % g.naux;
+            if (b > a) continue;
+            const double *wa = W + (long)a * g.ld, *wb = W + (long)b * g.ld;
+            double s0 = 0.0, s1 = 0.0;
+            for (int k = 0; k < g.n0; k += 2) {
+                s0 += wa[k] * wb[k];
+                s1 += wa[k + 1] * wb[k + 1];
+            }
+            const double sv = s0 + s1;
+            Go[a * g.naux + b] = sv;
+            Go[b * g.naux + a] = sv;
+        }
+        return;
+    }
     for (int pr = wave; pr < npairs; pr += 4) {
         int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
         while ((a + 1) * (a + 2) / 2 <= pr) ++a;
@@ -1258,6 +1277,15 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
     const double *G = p.G + (long)item * na * na;
     const double *ta = p.taux, *tt = p.taux + da;
     double *work = lds_work ? epi_dyn : p.work + (long)item * p.work_stride;
+    // k(aux point u, aux point v): table lookups when the item's lattice tables are at hand
+    const double *tab = p.tab ? p.tab + (long)item * g.maxstat * g.R : nullptr;
+    const double *sig = p.sig ? p.sig + (long)item * g.maxcp * g.npts : nullptr;
+    auto kaux = [&](int u, int v) -> double {   // u, v index taux: appended points then forecast points
+        if (tab)
+            return keval_lattice(P, tab, sig, g.R, g.npts, p.taux[u], p.taux[v],
+                                 abs(p.qpts[g.n0 + u] - p.qpts[g.n0 + v]), g.n0 + u, g.n0 + v);
+        return keval(P, sp, p.taux[u], p.taux[v]);
+    };
     double *LA = work;                  // [da x da]
     double *VA = LA + (long)da * da;    // [m x da]
     double *ldA = VA + (long)m * da;    // [da] log diag L_A
@@ -1266,7 +1294,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
         const int a = e / da, b = e % da;
         double v = 0.0;
         if (b <= a) {
-            v = keval(P, sp, ta[a], ta[b]) - (g.n0 ? G[a * na + b] : 0.0);
+            v = kaux(a, b) - (g.n0 ? G[a * na + b] : 0.0);
             if (a == b) v += nz;
         }
         LA[e] = v;
@@ -1293,7 +1321,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
     // V_A: one forecast row per thread, forward substitution along the appended points
     for (int i = tid; i < m; i += 64) {
         for (int a = 0; a < da; ++a) {
-            double s = keval(P, sp, tt[i], ta[a]) - (g.n0 ? G[(da + i) * na + a] : 0.0);
+            double s = kaux(da + i, a) - (g.n0 ? G[(da + i) * na + a] : 0.0);
             for (int pp = 0; pp < a; ++pp) s -= VA[i * da + pp] * LA[a * da + pp];
             VA[i * da + a] = s / LA[a * da + a];
         }
@@ -1304,7 +1332,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
         for (int e = tid; e < m * m; e += 64) {
             const int i = e / m, jj = e % m;
             if (jj > i) continue;
-            double s = keval(P, sp, tt[i], tt[jj]) - (g.n0 ? G[(da + i) * na + da + jj] : 0.0);
+            double s = kaux(da + i, da + jj) - (g.n0 ? G[(da + i) * na + da + jj] : 0.0);
             for (int a = 0; a < da; ++a) s -= VA[i * da + a] * VA[jj * da + a];
             if (i == jj && g.noise_on_new) s += nz;
             Sg[i * m + jj] = s;
