@@ -110,3 +110,10 @@ class KernelArray:
     @property
     def n_params(self):
         return [int(v) for v in self._npar]
+
+    def set_params(self, flat_params: np.ndarray, noise: np.ndarray) -> None:
+        """Overwrite every program's parameters in place (``flat_params``: their concatenation in
+        program order) and the noise variances; the opcodes stay.  For loops that re-evaluate the
+        same structures with new parameters (HMC leapfrogs)."""
+        self._params[:flat_params.size] = flat_params
+        self._rec["noise"][:self.n] = noise

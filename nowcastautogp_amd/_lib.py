@@ -346,17 +346,22 @@ class Context:
                                        iptr(comp), iptr(info)), "ngp_mixture_sample")
         return out, comp, info
 
-    def logml_grad_batch(self, programs, t, y):
-        ka = KernelArray(programs)
+    def logml_grad_flat(self, ka: KernelArray, t, y):
+        """``ngp_logml_grad_batch`` on a prepared kernel array; the gradients come back as ONE
+        vector (per program: d/d params in program order, then d/d noise), no per-program split."""
         t = as_f64(t)
         y, ldy = self._ymat(y, ka.n, t.size)
-        sizes = [p + 1 for p in ka.n_params]
-        grad = np.empty(int(sum(sizes)))
+        grad = np.empty(int(ka._npar.sum()) + ka.n)
         lm, info = np.empty(ka.n), np.zeros(ka.n, dtype=np.int32)
         _chk(load().ngp_logml_grad_batch(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy,
                                          dptr(lm), dptr(grad), iptr(info)),
              "ngp_logml_grad_batch")
-        offs = np.concatenate([[0], np.cumsum(sizes)])
+        return lm, grad, info
+
+    def logml_grad_batch(self, programs, t, y):
+        ka = KernelArray(programs)
+        lm, grad, info = self.logml_grad_flat(ka, t, y)
+        offs = np.concatenate([[0], np.cumsum(ka._npar + 1)])
         return lm, [grad[offs[i]:offs[i + 1]] for i in range(ka.n)], info
 
     # ---- staged ---------------------------------------------------------------------------

@@ -59,6 +59,14 @@ class HipEngine:
     def logml_grad(self, programs, t, y):
         return self.ctx.logml_grad_batch(programs, t, y)
 
+    def kernel_array(self, programs):
+        """The C array behind a list of programs, for loops that only change parameters."""
+        from ._abi import KernelArray
+        return KernelArray(programs)
+
+    def logml_grad_flat(self, ka, t, y):
+        return self.ctx.logml_grad_flat(ka, t, y)
+
     def predict(self, programs, t, y, t_new, noise_on_new=True):
         return self.ctx.predict_batch(programs, t, y, t_new, noise_on_new)
 
@@ -414,6 +422,13 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
     positive = (codes == gp.KIND_CODES["wildcard"]) | (codes == gp.KIND_CODES["period"])
     is_gamma, is_unit = codes == gp.KIND_CODES["gamma"], codes == gp.KIND_CODES["unit"]
 
+    is_param = np.ones(codes.size, dtype=bool)
+    is_param[last] = False
+    eng = model._eng()
+    ka = None
+    if hasattr(eng, "logml_grad_flat"):
+        ka = eng.kernel_array([(ops[k], np.zeros(sizes[k] - 1), 0.0) for k in range(P)])
+
     def sums(v):                                             # per-particle sums of a flat vector
         return np.bincount(seg, weights=v, minlength=P)
 
@@ -426,9 +441,13 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
         th[positive] = np.maximum(th[positive], 1e-12)
         th[is_gamma] = np.clip(th[is_gamma], 1e-9, 2.0 - 1e-9)
         th[is_unit] = np.clip(th[is_unit], 1e-9, 1.0 - 1e-9)
-        progs = [(ops[k], th[sl[k]][:-1], float(th[last[k]])) for k in range(P)]
-        lm, grads, info = model._eng().logml_grad(progs, t, y)
-        g = np.concatenate(grads)
+        if ka is not None:      # same structures, new parameters: refill the C array in place
+            ka.set_params(th[is_param], th[last])
+            lm, g, info = eng.logml_grad_flat(ka, t, y)
+        else:
+            progs = [(ops[k], th[sl[k]][:-1], float(th[last[k]])) for k in range(P)]
+            lm, grads, info = eng.logml_grad(progs, t, y)
+            g = np.concatenate(grads)
         with np.errstate(invalid="ignore", over="ignore"):
             ok = (np.asarray(info) == 0) & np.isfinite(lm) & (sums(~np.isfinite(g)) == 0)
             U = np.where(ok, -np.asarray(lm) + 0.5 * sums(z * z), np.inf)
