@@ -1275,7 +1275,6 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
     const int da = g.da, m = g.m, na = g.naux, Y = da + m;
     const double nz = P.noise + sp.jitter;
     const double *G = p.G + (long)item * na * na;
-    const double *ta = p.taux, *tt = p.taux + da;
     double *work = lds_work ? epi_dyn : p.work + (long)item * p.work_stride;
     // k(aux point u, aux point v): table lookups when the item's lattice tables are at hand
     const double *tab = p.tab ? p.tab + (long)item * g.maxstat * g.R : nullptr;
