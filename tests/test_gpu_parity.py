@@ -563,3 +563,20 @@ def test_randomised_differential_against_the_oracle(ctx):
                 assert nerr(grads[p], rg) < tol(1e-7, cond), (case, p, n)
     ctx.set_spec(NgpSpec(0, 0, 0, 0, 1e-5))
     assert worst > 0.0
+
+
+def test_kernel_array_refill_and_flat_gradient(ctx):
+    """The HMC fast path: one KernelArray whose parameters are overwritten in place, gradients as
+    one vector — must equal building everything anew."""
+    from nowcastautogp_amd._abi import KernelArray
+    w = make_workload("C1", n=150, P=5, D=1)
+    ka = KernelArray([(ops, np.zeros(len(params)), 0.0) for ops, params, _ in w.programs])
+    rng = np.random.Generator(np.random.PCG64(4))
+    for _ in range(3):
+        progs = [(ops, params * np.exp(0.05 * rng.standard_normal(len(params))), noise * 1.1)
+                 for ops, params, noise in w.programs]
+        ka.set_params(np.concatenate([p[1] for p in progs]), np.array([p[2] for p in progs]))
+        lm, g, info = ctx.logml_grad_flat(ka, w.t, w.y)
+        rlm, rg, rinfo = ctx.logml_grad_batch(progs, w.t, w.y)
+        assert not info.any() and not rinfo.any()
+        assert np.array_equal(lm, rlm) and np.array_equal(g, np.concatenate(rg))
