@@ -8,9 +8,9 @@ A *step* is one pass of the hot path over the whole batch: for every (particle, 
 the covariance matrix at n+d points is assembled from the item's kernel tree, factorised, and
 its log marginal likelihood + predictive mean/covariance are produced — i.e. exactly the work
 the reference's forecast_with_nowcasts does per scenario task (reference
-src/forecasting.jl:246-268: add_data! then predict_mvn on a deep-copied model).  In the headline
+src/forecasting.jl:133-155: add_data! then predict_mvn on a deep-copied model).  In the headline
 ("distinct") mode every one of the 12,800 items carries its own kernel parameters (the
-per-draw HMC-refined parameters of forecast_n_hmc, src/forecasting.jl:176-181), so nothing is
+per-draw HMC-refined parameters of forecast_n_hmc, src/forecasting.jl:63-68), so nothing is
 deduplicated: 12,800 factorisations per step.  ``value`` = items / second, whole job.
 
 Also reported (extra keys, never mixed into ``value``/``roofline``): the shared-K mode the
@@ -43,7 +43,7 @@ def F_logml(n):
 
 def cpu_baseline(w, progs, Y, sample_items, threads):
     """The numpy/LAPACK oracle ("port"), run as the reference runs: BLAS threads = 1
-    (src/forecasting.jl:114-123), one worker thread per host core over items."""
+    (src/forecasting.jl:1-10), one worker thread per host core over items."""
     from concurrent.futures import ThreadPoolExecutor
 
     from threadpoolctl import threadpool_limits
@@ -68,8 +68,8 @@ def cpu_baseline(w, progs, Y, sample_items, threads):
 def fit_forecast_wallclock(w, device):
     """End-to-end wall-clock of the two reference call sites through the host mirror and the HIP
     engine: make_and_fit_model (SMC over 10 data-annealing steps, structure MH + HMC rejuvenation)
-    then forecast_with_nowcasts over all scenarios (reference src/make_and_fit_model.jl:98-113,
-    src/forecasting.jl:230-280).  Sampler settings are deliberately light (the step that matters
+    then forecast_with_nowcasts over all scenarios (reference src/make_and_fit_model.jl:78-93,
+    src/forecasting.jl:117-167).  Sampler settings are deliberately light (the step that matters
     for throughput is the batched hot path timed above); they are printed with the result."""
     import datetime as dt
 

@@ -6,9 +6,9 @@
  * log-marginal-likelihood -> posterior-predictive solves, batched over SMC
  * particles x nowcast scenarios.  Reference call sites (paths relative to the
  * reference checkout):
- *     src/make_and_fit_model.jl:104-111   GPModel(...), linear_schedule, fit_smc!
- *     src/forecasting.jl:159-160,178-180  predict_mvn + rand
- *     src/forecasting.jl:246-262          GPModel(dict), add_data!, maybe_resample!,
+ *     src/make_and_fit_model.jl:84-91   GPModel(...), linear_schedule, fit_smc!
+ *     src/forecasting.jl:46-47,65-67  predict_mvn + rand
+ *     src/forecasting.jl:133-149          GPModel(dict), add_data!, maybe_resample!,
  *                                         mcmc_structure!, mcmc_parameters!
  * The reference has no FFI of its own (it is pure Julia on AutoGP.jl); the
  * entry points below are what a Julia `ccall` / Python `ctypes` shim binds in
@@ -21,14 +21,14 @@
  *   - all pointers are caller-owned HOST memory, valid for the duration of the
  *     call (or, for staged jobs, until ngp_job_run returns for inputs and
  *     ngp_job_fetch returns for outputs); the library retains none of them.
- *   - Float64 everywhere (src/forecasting.jl:175); dense outputs are row-major
+ *   - Float64 everywhere (src/forecasting.jl:62); dense outputs are row-major
  *     and symmetric where that applies, so Julia's column-major view is the same
  *     matrix.
  *   - numerical failure is reported PER ITEM in info[] with LAPACK potrf
  *     semantics (k > 0: leading minor k is not positive definite), which the
- *     shim rethrows as PosDefException(k) (src/make_and_fit_model.jl:26-28).
+ *     shim rethrows as PosDefException(k) (src/make_and_fit_model.jl:6-8).
  *   - re-entrant: may be entered concurrently from many host threads
- *     (Threads.@spawn per scenario, src/forecasting.jl:244-245); calls on one
+ *     (Threads.@spawn per scenario, src/forecasting.jl:131-132); calls on one
  *     ctx are serialised by a blocking mutex, never a spin.
  */
 #ifndef NGP_H
@@ -66,9 +66,28 @@ typedef struct ngp_spec {
     int32_t se_form;       /* 0: a*exp(-0.5*d^2/l^2)       1: a*exp(-0.5*d^2/l)        */
     int32_t periodic_form; /* 0: a*exp(-(2/l^2)*sin^2(pi*d/p))  1: a*exp(-(2/l)*sin^2(pi*d/p)) */
     int32_t cp_form;       /* 0: sigma(x)=.5*(1+tanh((loc-x)/scale))  1: tanh((x-loc)/scale) */
-    int32_t reserved;
+    int32_t precision;     /* NGP_PREC_F64 (default) or NGP_PREC_MIXED, see below          */
     double  jitter;        /* added to the diagonal next to the noise variance */
+    /* ---- NGP_PREC_MIXED only (BASELINE config C5: long histories) ---------------------
+     * The trailing updates of the blocked Cholesky run on the fp32 matrix cores wherever
+     * that is provably harmless and in fp64 elsewhere: the product of two 64x64 tiles of L
+     * goes through v_mfma_f32_32x32x2_f32 (operands rounded to fp32) iff
+     *     64 * 2^-24 * max|tile A| * max|tile B|  <=  mixed_tau * (noise + jitter),
+     * i.e. iff its rounding error is below mixed_tau of the smallest pivot the matrix can
+     * have; everything else (the diagonal blocks, the panel solves, the accumulators and
+     * the stored factor) stays fp64.  The Gram matrix X K^-1 X' of the appended / forecast
+     * / data rows is then refined against the fp64 covariance (G <- A X' + (X - A K) A',
+     * A += (X - A K) (L L')^-1) until the predicted remaining relative error is below
+     * refine_tol or refine_max steps were taken; an item that does not get there is
+     * reported with info = NGP_INFO_NOT_REFINED.  log det comes from the factor itself.   */
+    double  mixed_tau;     /* default 1e-5                                              */
+    double  refine_tol;    /* default 1e-9                                              */
+    int32_t refine_max;    /* default 3 (0: no refinement)                              */
+    int32_t reserved;
 } ngp_spec;
+enum { NGP_PREC_F64 = 0, NGP_PREC_MIXED = 1 };
+/* info[] < 0: not a pivot index */
+#define NGP_INFO_NOT_REFINED (-2)
 
 /* One particle's covariance kernel: the tree in postfix (RPN) order
  * (left subtree, right subtree, operator); params are consumed in RPN order. */
@@ -107,8 +126,8 @@ ngp_status  ngp_kernel_check(const ngp_kernel *k);
 /* ---- covariance assembly (diagnostic / small blocks) ---------------------
  * out[b] (n1 x n2, row-major) = k_b(t1_i, t2_j) (+ (noise_b + jitter) on the
  * diagonal i==j when add_diag != 0).  Replaces AutoGP's covariance-matrix
- * builder used under fit_smc!/predict_mvn (src/make_and_fit_model.jl:111,
- * src/forecasting.jl:159).                                                   */
+ * builder used under fit_smc!/predict_mvn (src/make_and_fit_model.jl:91,
+ * src/forecasting.jl:46).                                                   */
 ngp_status ngp_cov_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
                          int32_t n1, const double *t1, int32_t n2, const double *t2,
                          int32_t add_diag, double *out);
@@ -117,7 +136,7 @@ ngp_status ngp_cov_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
  * logml[b] = log N(y_b | 0, K_b(t,t) + (noise_b + jitter) I), b = 0..B-1.
  * y is [B x n] with row stride ldy (ldy == 0: one y shared by all items).
  * This is the per-particle evaluation inside fit_smc! / add_data! /
- * mcmc_structure! (src/make_and_fit_model.jl:111, src/forecasting.jl:248,259). */
+ * mcmc_structure! (src/make_and_fit_model.jl:91, src/forecasting.jl:135,146). */
 ngp_status ngp_logml_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
                            int32_t n, const double *t, const double *y, int64_t ldy,
                            double *logml, int32_t *info);
@@ -126,7 +145,7 @@ ngp_status ngp_logml_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
  * Per item: mu[b] (m), sigma[b] (m x m) of  f(t_new) | y_b  (+ observation
  * noise on the new points when noise_on_new != 0), and logml[b] (may be NULL).
  * Replaces the per-particle conditional MVN inside AutoGP.predict_mvn
- * (src/forecasting.jl:159,179).                                              */
+ * (src/forecasting.jl:46,66).                                              */
 ngp_status ngp_predict_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
                              int32_t n, const double *t, const double *y, int64_t ldy,
                              int32_t m, const double *t_new, int32_t noise_on_new,
@@ -134,7 +153,7 @@ ngp_status ngp_predict_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
 
 /* ---- nowcast fan-out ------------------------------------------------------
  * The whole body of forecast_with_nowcasts' per-scenario task for the default
- * n_mcmc = n_hmc = 0 path (src/forecasting.jl:246-268), for P particles and D
+ * n_mcmc = n_hmc = 0 path (src/forecasting.jl:133-155), for P particles and D
  * scenarios at once.  All scenarios share the appended dates
  * (src/create_nowcast_data.jl:36-37), and K does not depend on y, so each
  * particle is factorised ONCE; per scenario only the d appended observations
@@ -160,13 +179,13 @@ ngp_status ngp_nowcast_batch(ngp_ctx *ctx, int32_t P, const ngp_kernel *kernels,
  * grad[b] has n_params_b + 1 entries: d logml / d params (RPN order) followed
  * by d logml / d noise; items are packed back to back (offsets = running sum of
  * n_params_b + 1).  Needed by the HMC moves of mcmc_parameters! / fit_smc!
- * (src/forecasting.jl:178,261; src/make_and_fit_model.jl:111).               */
+ * (src/forecasting.jl:65,148; src/make_and_fit_model.jl:91).               */
 ngp_status ngp_logml_grad_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels,
                                 int32_t n, const double *t, const double *y, int64_t ldy,
                                 double *logml, double *grad, int32_t *info);
 
 /* ---- particle weights -----------------------------------------------------
- * maybe_resample! arithmetic (src/forecasting.jl:251-254): normalise P
+ * maybe_resample! arithmetic (src/forecasting.jl:138-141): normalise P
  * log-weights (logsumexp), effective sample size 1 / sum w^2.  In a multi-GPU
  * run the caller all-gathers the per-rank log-weights first (the only
  * collective on the path) and passes the gathered vector.
@@ -196,10 +215,16 @@ ngp_status ngp_nowcast_stage(ngp_ctx *ctx, int32_t P, const ngp_kernel *kernels,
 ngp_status ngp_job_run(ngp_job *job);
 ngp_status ngp_job_fetch(ngp_job *job, double *logml_base, double *logml_full,
                          double *mu, double *sigma, int32_t *info);
+/* NGP_PREC_MIXED jobs, after ngp_job_run (any pointer may be NULL; all [B]):
+ *   refine_steps  refinement steps taken for the item (0 for an fp64 job)
+ *   refine_delta  relative size of the last correction applied to its Gram matrix
+ *   frac_f32      share of its tile products that ran on the fp32 matrix cores         */
+ngp_status ngp_job_mixed_stats(ngp_job *job, int32_t *refine_steps, double *refine_delta,
+                               double *frac_f32);
 void       ngp_job_destroy(ngp_job *job);
 
 /* ---- mixture sampling on the device -------------
- * predict_mvn(...) |> rand of the reference (src/forecasting.jl:160, 180) for S
+ * predict_mvn(...) |> rand of the reference (src/forecasting.jl:47, 67) for S
  * mixtures over the same P components at once (S = nowcast scenarios): component
  * k ~ Categorical(w[s][.]), then  mu[k][s][.] + chol(sigma[k]) z,  z ~ N(0, I).
  *   w     [S x P]      mixture weights, each row sums to 1 (ngp_weights_normalize)
@@ -219,7 +244,7 @@ ngp_status ngp_mixture_sample(ngp_ctx *ctx, int32_t P, int32_t S, int32_t m,
 /* ---- cached factor ------------------------------
  * A fitted model is queried many times with the same particles and the same
  * training data: forecast() on several date grids, forecast_with_nowcasts()
- * after it (src/forecasting.jl:159, 248).  ngp_factor_create factorises the P
+ * after it (src/forecasting.jl:46, 135).  ngp_factor_create factorises the P
  * training covariances ONCE and keeps L (and the block inverses the solves
  * use) resident on the device; a query then only fills its aux rows (appended
  * points, forecast points, y) and sweeps them through L: O(n^2 (d + m)) per
@@ -247,8 +272,11 @@ void       ngp_factor_destroy(ngp_factor *f);
  * launched on.  Classes: 0 = chol_col_glds_kernel (fat steps: trailing-update
  * GEMM + fused solve, the dominant kernel), 1 = chol_diag, 2 = gram,
  * 3 = epilogue, 4 = cov fill, 5 = gradient kernels, 6 = chol_col_kernel (thin /
- * full steps, aux solves of a resident factor), 7 = aux_update_kernel.        */
-#define NGP_NUM_KERNEL_CLASSES 8
+ * full steps, aux solves of a resident factor), 7 = aux_update_kernel,
+ * 8 = diag_ahead_kernel (side stream, overlaps classes 1 and 6), 9 = the
+ * mixed-precision fat steps (chol_col_glds_kernel<MIXED>), 10 = Gram refinement
+ * of NGP_PREC_MIXED (backward sweep, covariance apply, small products).        */
+#define NGP_NUM_KERNEL_CLASSES 12
 typedef struct ngp_profile {
     double   ms[NGP_NUM_KERNEL_CLASSES];       /* summed device time per class */
     int64_t  launches[NGP_NUM_KERNEL_CLASSES]; /* kernel launches per class    */
@@ -271,6 +299,9 @@ ngp_status ngp_microbench_mfma_f64_detail(ngp_ctx *ctx, int32_t iters, int32_t b
  * v_mfma_f64_4x4x4_4b_f64 gathered back to the 16x16x4 C/D layout (the k-loop fast path).
  * The caller compares both halves with A @ B.  D must hold 512 doubles.                 */
 ngp_status ngp_selftest_mfma_layout(ngp_ctx *ctx, const double *A, const double *B, double *D);
+/* The same for the fp32 form of the mixed-precision path: D[32x32] = A[32x2] B[2x32] through one
+ * v_mfma_f32_32x32x2_f32 (all row-major floats).                                          */
+ngp_status ngp_selftest_mfma_f32_layout(ngp_ctx *ctx, const float *A, const float *B, float *D);
 /* HBM streaming-write microbenchmark (GB/s) used to anchor the fill roofline. */
 ngp_status ngp_microbench_hbm(ngp_ctx *ctx, int64_t bytes, double *write_gbs, double *copy_gbs);
 

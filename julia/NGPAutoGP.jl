@@ -1,5 +1,5 @@
 # NGPAutoGP.jl — Julia-side binding of libngp (include/ngp.h) behind the AutoGP surface that
-# NowcastAutoGP calls (src/make_and_fit_model.jl:104-111, src/forecasting.jl:159-268).
+# NowcastAutoGP calls (src/make_and_fit_model.jl:84-91, src/forecasting.jl:46-155).
 #
 # STATUS: written against include/ngp.h, NEVER EXECUTED — no `julia` binary exists in the build
 # container or on the GPU box.  The Python package `nowcastautogp_amd` is the executed, tested
@@ -114,7 +114,7 @@ function predict_batch(c::Context, progs::Vector{Program}, t::Vector{Float64},
     return mu, sigma, lm, info
 end
 
-"add_data! + predict_mvn for ALL scenarios of ALL particles in one call (src/forecasting.jl:246-268)."
+"add_data! + predict_mvn for ALL scenarios of ALL particles in one call (src/forecasting.jl:133-155)."
 function nowcast_batch(c::Context, progs::Vector{Program}, t::Vector{Float64}, y::Vector{Float64},
                        t_add::Vector{Float64}, y_add::Matrix{Float64},  # d x D (column = scenario)
                        t_new::Vector{Float64}; noise_on_new::Bool = true)
@@ -200,7 +200,7 @@ function weights_normalize(logw::Vector{Float64})
     return w, ess[], ln[]
 end
 
-"info[b] > 0  =>  PosDefException(info[b]), as the reference surfaces it (src/make_and_fit_model.jl:26-28)."
+"info[b] > 0  =>  PosDefException(info[b]), as the reference surfaces it (src/make_and_fit_model.jl:6-8)."
 raise_if_not_posdef(info) = (k = findfirst(!=(0), info); k === nothing || throw(PosDefException(info[k])))
 
 # ---- AutoGP surface (thin; the SMC orchestration is the one in nowcastautogp_amd/autogp.py) -------

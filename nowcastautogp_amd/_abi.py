@@ -14,7 +14,9 @@ NGP_MAX_OPS = 64
 NGP_MAX_PARAMS = 96
 NGP_MAX_STACK = 16
 NGP_MAX_AUX = 192
-NGP_NUM_KERNEL_CLASSES = 8
+NGP_NUM_KERNEL_CLASSES = 12
+NGP_PREC_F64, NGP_PREC_MIXED = 0, 1
+NGP_INFO_NOT_REFINED = -2
 
 # parameters consumed per opcode (index = opcode), include/ngp.h enum
 N_PARAMS = (0, 1, 3, 2, 3, 3, 0, 0, 2)
@@ -28,8 +30,12 @@ class NgpSpec(C.Structure):
         ("se_form", C.c_int32),
         ("periodic_form", C.c_int32),
         ("cp_form", C.c_int32),
-        ("reserved", C.c_int32),
+        ("precision", C.c_int32),
         ("jitter", C.c_double),
+        ("mixed_tau", C.c_double),
+        ("refine_tol", C.c_double),
+        ("refine_max", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -52,8 +58,10 @@ class NgpProfile(C.Structure):
     ]
 
 
-def default_spec() -> NgpSpec:
-    return NgpSpec(0, 0, 0, 0, 1e-5)
+def default_spec(precision: int = NGP_PREC_F64) -> NgpSpec:
+    """The library defaults (``ngp_default_spec``), optionally with the mixed-precision
+    factorisation of BASELINE config C5 switched on."""
+    return NgpSpec(0, 0, 0, int(precision), 1e-5, 1e-5, 1e-9, 3, 0)
 
 
 def as_f64(a) -> np.ndarray:

@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NGP_LIB") or os.path.join(_HERE, "libngp.so")  # NGP_LIB: A/B builds
 
 KERNEL_CLASSES = ("chol_col", "chol_diag", "gram", "epilogue", "fill", "grad", "chol_col_thin",
-                  "aux_update")
+                  "aux_update", "diag_ahead", "chol_col_mixed", "refine", "reserved")
 
 # every symbol include/ngp.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = (
@@ -28,9 +28,10 @@ SYMBOLS = (
     "ngp_strerror", "ngp_version", "ngp_kernel_check", "ngp_cov_batch", "ngp_logml_batch",
     "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
-    "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
+    "ngp_job_mixed_stats", "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
     "ngp_factor_destroy", "ngp_mixture_sample", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
     "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
+    "ngp_selftest_mfma_f32_layout",
 )
 
 
@@ -42,7 +43,7 @@ class NgpError(RuntimeError):
 
 class PosDefException(ArithmeticError):
     """Leading minor ``k`` of a covariance matrix is not positive definite (LAPACK potrf info;
-    the reference surfaces this as Julia's PosDefException, src/make_and_fit_model.jl:26-28)."""
+    the reference surfaces this as Julia's PosDefException, src/make_and_fit_model.jl:6-8)."""
 
     def __init__(self, k: int, item: int):
         self.info, self.item = k, item
@@ -88,6 +89,7 @@ def load():
                                     i32, C.POINTER(vp)]),
         "ngp_job_run": (i32, [vp]),
         "ngp_job_fetch": (i32, [vp, f64p, f64p, f64p, f64p, i32p]),
+        "ngp_job_mixed_stats": (i32, [vp, i32p, f64p, f64p]),
         "ngp_job_destroy": (None, [vp]),
         "ngp_factor_create": (i32, [vp, i32, KP, i32, f64p, f64p, i64, C.POINTER(vp)]),
         "ngp_factor_logml": (i32, [vp, f64p, i32p]),
@@ -103,6 +105,8 @@ def load():
         "ngp_microbench_mfma_f64_detail": (i32, [vp, i32, i32, f64p]),
         "ngp_microbench_hbm": (i32, [vp, i64, f64p, f64p]),
         "ngp_selftest_mfma_layout": (i32, [vp, f64p, f64p, f64p]),
+        "ngp_selftest_mfma_f32_layout": (i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                               C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -129,7 +133,7 @@ def kernel_check(program) -> int:
 
 
 def weights_normalize(logw):
-    """maybe_resample! arithmetic (reference src/forecasting.jl:251-254); host-side, P doubles."""
+    """maybe_resample! arithmetic (reference src/forecasting.jl:138-141); host-side, P doubles."""
     logw = as_f64(logw)
     w = np.empty(logw.size)
     ess, ln = C.c_double(), C.c_double()
@@ -163,6 +167,15 @@ class Job:
         _chk(load().ngp_job_fetch(self._h, dptr(lb), dptr(lf), _nullable(mu), _nullable(sg),
                                   iptr(info)), "ngp_job_fetch")
         return dict(logml_base=lb, logml_full=lf, mu=mu, sigma=sg, info=info)
+
+    def mixed_stats(self):
+        """NGP_PREC_MIXED jobs: per item the refinement steps taken, the size of the last
+        correction and the share of tile products that ran on the fp32 matrix cores."""
+        steps = np.zeros(self.P, dtype=np.int32)
+        delta, frac = np.zeros(self.P), np.zeros(self.P)
+        _chk(load().ngp_job_mixed_stats(self._h, iptr(steps), dptr(delta), dptr(frac)),
+             "ngp_job_mixed_stats")
+        return dict(refine_steps=steps, refine_delta=delta, frac_f32=frac)
 
     def close(self):
         # the handle points into its context: a context closed first has already closed us
@@ -428,6 +441,17 @@ class Context:
         _chk(load().ngp_microbench_hbm(self._h, nbytes, C.byref(w), C.byref(c)),
              "ngp_microbench_hbm")
         return float(w.value), float(c.value)
+
+    def selftest_mfma_f32_layout(self, A, B):
+        """D = A[32x2] B[2x32] through one v_mfma_f32_32x32x2_f32 (mixed-precision k-loop maps)"""
+        A = np.ascontiguousarray(A, dtype=np.float32).reshape(32, 2)
+        B = np.ascontiguousarray(B, dtype=np.float32).reshape(2, 32)
+        D = np.empty((32, 32), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        _chk(load().ngp_selftest_mfma_f32_layout(self._h, A.ctypes.data_as(fp),
+                                                 B.ctypes.data_as(fp), D.ctypes.data_as(fp)),
+             "ngp_selftest_mfma_f32_layout")
+        return D
 
     def selftest_mfma_layout(self, A, B):
         """returns (D via v_mfma_f64_16x16x4, D via 4 rotated v_mfma_f64_4x4x4 + gather)"""

@@ -2,16 +2,16 @@
 
 Every symbol below stands where the reference calls into AutoGP.jl:
 
-    GPModel(ds, y; n_particles, config)      src/make_and_fit_model.jl:104-107
-    Schedule.linear_schedule(n, p)           src/make_and_fit_model.jl:110
-    fit_smc!(model; schedule, n_mcmc, n_hmc) src/make_and_fit_model.jl:111
-    add_data!(model, ds, y)                  src/forecasting.jl:248
-    maybe_resample!(model, ess)              src/forecasting.jl:251-254
-    num_particles(model)                     src/forecasting.jl:253
-    mcmc_structure!(model, n_mcmc, n_hmc)    src/forecasting.jl:259
-    mcmc_parameters!(model, n_hmc)           src/forecasting.jl:178,261
-    predict_mvn(model, dates) -> rand        src/forecasting.jl:159-160,179-180
-    Dict(model) / GPModel(dict)              src/forecasting.jl:241,246
+    GPModel(ds, y; n_particles, config)      src/make_and_fit_model.jl:84-87
+    Schedule.linear_schedule(n, p)           src/make_and_fit_model.jl:90
+    fit_smc!(model; schedule, n_mcmc, n_hmc) src/make_and_fit_model.jl:91
+    add_data!(model, ds, y)                  src/forecasting.jl:135
+    maybe_resample!(model, ess)              src/forecasting.jl:138-141
+    num_particles(model)                     src/forecasting.jl:140
+    mcmc_structure!(model, n_mcmc, n_hmc)    src/forecasting.jl:146
+    mcmc_parameters!(model, n_hmc)           src/forecasting.jl:65,148
+    predict_mvn(model, dates) -> rand        src/forecasting.jl:46-47,66-67
+    Dict(model) / GPModel(dict)              src/forecasting.jl:128,133
 
 The arithmetic (covariance assembly, Cholesky, log marginal likelihoods, their gradients,
 predictive solves) is NOT here: it is the HIP library behind ``engine`` (``_lib.Context`` through
@@ -111,7 +111,7 @@ def default_engine():
 
 # ---------------------------------------------------------------------------------------------
 # transforms (AutoGP rescales dates onto [0,1] — reference docs/vignettes/setting-priors.jl:71 —
-# and y by its range — reference src/make_and_fit_model.jl:26-27; exact affine map [RECALLED])
+# and y by its range — reference src/make_and_fit_model.jl:6-7; exact affine map [RECALLED])
 # ---------------------------------------------------------------------------------------------
 def to_days(ds) -> np.ndarray:
     """dates -> integer days (datetime.date / numpy datetime64 / numbers accepted)."""
@@ -150,7 +150,7 @@ def _y_transform(y: np.ndarray) -> LinearTransform:
     lo, hi = float(y.min()), float(y.max())
     if not hi > lo:
         # the reference documents this failure as a PosDefException (issue #51,
-        # src/make_and_fit_model.jl:26-28); _stabilize_for_fit jitters flat data before it gets here
+        # src/make_and_fit_model.jl:6-8); _stabilize_for_fit jitters flat data before it gets here
         raise PosDefException(1, 0)
     slope = 2.0 / (hi - lo)
     return LinearTransform(slope, -slope * (hi + lo) / 2.0)
@@ -161,7 +161,7 @@ class Schedule:
     @staticmethod
     def linear_schedule(n: int, percent: float) -> List[int]:
         """Cumulative observation counts of the data-annealing steps: step = max(1, round(p n))
-        up to n (reference src/make_and_fit_model.jl:109-110 clamps p >= 1/n)."""
+        up to n (reference src/make_and_fit_model.jl:89-90 clamps p >= 1/n)."""
         if n <= 0:
             raise ValueError("n must be positive")
         step = max(1, int(round(percent * n)))
@@ -264,7 +264,7 @@ class GPModel:
             self.__dict__["_fcache"] = cache
         return cache.factor
 
-    # -- Dict(model) / GPModel(dict)  (reference src/forecasting.jl:241,246) ----------------------
+    # -- Dict(model) / GPModel(dict)  (reference src/forecasting.jl:128,133) ----------------------
     def to_dict(self) -> dict:
         return {
             "config": self.config,   # kept by identity, like the reference's model.config === cfg
@@ -318,7 +318,7 @@ def effective_sample_size(model: GPModel) -> float:
 
 def maybe_resample(model: GPModel, ess_threshold: float) -> bool:
     """Resample (multinomial) when ESS < ess_threshold (an absolute count, as the reference
-    passes ``ess_threshold * num_particles``, src/forecasting.jl:251-254).  Weights reset to
+    passes ``ess_threshold * num_particles``, src/forecasting.jl:138-141).  Weights reset to
     uniform.  Across ranks: all-gather of log-weights, identical ancestors everywhere, particle
     descriptors exchanged — no matrix moves."""
     w_loc, ess = _normalized_weights(model)
@@ -538,7 +538,7 @@ def fit_smc(model: GPModel, *, schedule: Sequence[int], n_mcmc: int, n_hmc: int,
 
 def add_data(model: GPModel, ds, y) -> None:
     """Append observations; particle log-weights move by logml(n+d) - logml(n)
-    (reference src/forecasting.jl:248)."""
+    (reference src/forecasting.jl:135)."""
     ds, y = list(ds), np.asarray(y, dtype=np.float64)
     if len(ds) != y.size:
         raise ValueError("ds and y must have the same length")
@@ -558,7 +558,7 @@ def add_data(model: GPModel, ds, y) -> None:
 # ---------------------------------------------------------------------------------------------
 class MixtureMVN:
     """Weighted mixture of per-particle multivariate normals (what predict_mvn returns);
-    ``rand(k)`` -> [m, k], ``rand()`` -> [m] (reference src/forecasting.jl:160,180)."""
+    ``rand(k)`` -> [m, k], ``rand()`` -> [m] (reference src/forecasting.jl:47,67)."""
 
     def __init__(self, means, covs, weights, rng, sampler=None):
         self.means, self.covs = np.asarray(means, float), np.asarray(covs, float)

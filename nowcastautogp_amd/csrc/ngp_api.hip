@@ -19,6 +19,15 @@ using namespace ngp;
     } while (0)
 
 namespace {
+struct ScopedEvent {   // destroyed on every exit path of the microbenchmarks
+    hipEvent_t e = nullptr;
+    ScopedEvent() { (void)hipEventCreate(&e); }
+    ~ScopedEvent() { if (e) (void)hipEventDestroy(e); }
+    operator hipEvent_t() const { return e; }
+};
+}  // namespace
+
+namespace {
 
 constexpr int k_nparams[10] = {0, 1, 3, 2, 3, 3, 0, 0, 2, 2};
 
@@ -172,11 +181,6 @@ struct ngp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // diag-ahead tiles run beside the main schedule
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // second lane: with several chunks in a job, alternate chunks run on a second stream so the
-    // latency-bound chol_diag / HBM-write-bound fill of one chunk overlap the MFMA-bound chol_col
-    // of the other
-    hipStream_t stream2 = nullptr, side2 = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_lane2 = nullptr;
     ngp_spec spec{};
     std::mutex mu;
     bool profiling = false;
@@ -216,7 +220,7 @@ struct ngp_ctx {
 };
 
 static DevSpec dev_spec(const ngp_spec &s) {
-    return DevSpec{s.se_form, s.periodic_form, s.cp_form, 0, s.jitter};
+    return DevSpec{s.se_form, s.periodic_form, s.cp_form, s.precision, s.jitter, s.mixed_tau};
 }
 
 extern "C" void ngp_default_spec(ngp_spec *s) {
@@ -224,8 +228,12 @@ extern "C" void ngp_default_spec(ngp_spec *s) {
     s->se_form = 0;
     s->periodic_form = 0;
     s->cp_form = 0;
-    s->reserved = 0;
+    s->precision = NGP_PREC_F64;
     s->jitter = 1e-5;
+    s->mixed_tau = 1e-5;
+    s->refine_tol = 1e-9;
+    s->refine_max = 3;
+    s->reserved = 0;
 }
 
 extern "C" const char *ngp_version(void) { return "libngp 0.1.0 (gfx950)"; }
@@ -271,14 +279,6 @@ extern "C" ngp_status ngp_ctx_create(int32_t device, ngp_ctx **out) {
         delete c;
         return NGP_ERR_NO_DEVICE;
     }
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_lane2, hipEventDisableTiming) != hipSuccess) {
-        delete c;
-        return NGP_ERR_NO_DEVICE;
-    }
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->mem_cap = (size_t)(0.6 * (double)fr);
     else c->mem_cap = (size_t)8 << 30;
@@ -296,11 +296,6 @@ extern "C" void ngp_ctx_destroy(ngp_ctx *c) {
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->side2) { (void)hipStreamSynchronize(c->side2); (void)hipStreamDestroy(c->side2); }
-    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
-    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
-    if (c->ev_lane2) (void)hipEventDestroy(c->ev_lane2);
     delete c;
 }
 
@@ -309,12 +304,17 @@ extern "C" ngp_status ngp_set_spec(ngp_ctx *c, const ngp_spec *s) {
     if (s->se_form < 0 || s->se_form > 1 || s->periodic_form < 0 || s->periodic_form > 1 ||
         s->cp_form < 0 || s->cp_form > 1 || !(s->jitter >= 0.0))
         return NGP_ERR_ARG;
+    if (s->precision != NGP_PREC_F64 && s->precision != NGP_PREC_MIXED) return NGP_ERR_ARG;
+    if (s->precision == NGP_PREC_MIXED &&
+        (!(s->mixed_tau >= 0.0) || !(s->refine_tol > 0.0) || s->refine_max < 0 || s->refine_max > 16))
+        return NGP_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     c->spec = *s;
     return NGP_OK;
 }
 extern "C" ngp_status ngp_get_spec(const ngp_ctx *c, ngp_spec *s) {
     if (!c || !s) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(const_cast<ngp_ctx *>(c)->mu);
     *s = c->spec;
     return NGP_OK;
 }
@@ -354,6 +354,11 @@ struct ngp_job {
     double *logml_base = nullptr, *logml_full = nullptr, *mu = nullptr, *sigma = nullptr;
     int64_t work_stride = 0;
     std::vector<void *> owned;
+    // the spec the job was staged under: a later ngp_set_spec does not reach a staged job
+    ngp_spec spec{};
+    // NGP_PREC_MIXED: per item, filled by ngp_job_run
+    std::vector<int32_t> refine_steps;
+    std::vector<double> refine_delta, frac32;
 };
 
 namespace {
@@ -364,14 +369,23 @@ struct EventTimer {  // HIP events on the launch stream, resolved after the job'
     bool on;
     hipStream_t s;
     EventTimer(bool on_, hipStream_t s_) : on(on_), s(s_) {}
-    template <class F> void run(int cls, double flops, double bytes, F &&f) {
+    ~EventTimer() {   // an error path left before resolve()
+        for (auto &r : recs) {
+            (void)hipEventDestroy(r.a);
+            (void)hipEventDestroy(r.b);
+        }
+    }
+    // `on_stream`: the stream f launches on when it is not the timer's own (diag-ahead tiles)
+    template <class F> void run(int cls, double flops, double bytes, F &&f,
+                                hipStream_t on_stream = nullptr) {
         if (!on) { f(); return; }
+        hipStream_t es = on_stream ? on_stream : s;
         Rec r{cls, nullptr, nullptr, flops, bytes};
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
-        (void)hipEventRecord(r.a, s);
+        (void)hipEventRecord(r.a, es);
         f();
-        (void)hipEventRecord(r.b, s);
+        (void)hipEventRecord(r.b, es);
         recs.push_back(r);
     }
     void resolve(ngp_profile &p) {
@@ -399,15 +413,14 @@ struct Lane {
     hipStream_t main, side;
     hipEvent_t fork, join;
 };
-inline Lane lane_of(ngp_ctx *c, int i) {
-    return i == 0 ? Lane{c->stream, c->side, c->ev_fork, c->ev_join}
-                  : Lane{c->stream2, c->side2, c->ev_fork2, c->ev_join2};
-}
+inline Lane lane_of(ngp_ctx *c) { return Lane{c->stream, c->side, c->ev_fork, c->ev_join}; }
 
 // dinv_step != 0: block column jj writes / reads its M at p.dinv + jj * dinv_step (cached factor:
 // every M_j is kept); 0: one buffer reused by every step.
+// sp != null and p0.L32 set: mixed-precision job (fat steps on chol_col_glds_kernel<MIXED>, class 9).
 void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p0, int bc, EventTimer &tm,
-                  size_t dinv_step = 0) {
+                  size_t dinv_step = 0, const DevSpec *sp = nullptr) {
+    const bool mixed = sp != nullptr && p0.L32 != nullptr;
     hipStream_t s = ln.main;
     const double nrows_aux = (double)g.naux;
     bool ahead_pending = false;
@@ -443,12 +456,14 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p0, int bc,
         }
         // class 0: the LDS-DMA kernel of the fat steps (the dominant kernel, the roofline figure);
         // class 6: the direct-load kernel of the thin / full steps
-        tm.run(fat ? 0 : 6, bc * fl, bc * by,
-               [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, s); });
+        tm.run(fat ? (mixed ? 9 : 0) : 6, bc * fl, bc * by,
+               [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, s, sp); });
         if (ahead && jj > 0) {
             (void)hipEventRecord(ln.fork, s);
             (void)hipStreamWaitEvent(ln.side, ln.fork, 0);
-            launch_diag_ahead(g, p0, bc, jj, ln.side);
+            // class 8: on the side stream, beside chol_diag(jj+1) / the thin step of jj+1
+            tm.run(8, bc * (double)NB * NB * k, bc * 8.0 * NB * k,
+                   [&] { launch_diag_ahead(g, p0, bc, jj, ln.side); }, ln.side);
             (void)hipEventRecord(ln.join, ln.side);
             ahead_pending = true;
         }
@@ -531,6 +546,7 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     j->ctx = c;
     j->g = g;
     j->n = n;
+    j->spec = c->spec;
     ngp_status st = NGP_OK;
     auto fail = [&](ngp_status s) {
         for (void *p : j->owned) c->release(p);
@@ -594,6 +610,97 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
 
 }  // namespace
 
+namespace {
+
+// Device buffers of the Gram refinement of one chunk (NGP_PREC_MIXED).
+struct RefineBufs {
+    double *X = nullptr, *A = nullptr, *R = nullptr;   // [Bc][naux_pad][n0]
+    double *S = nullptr, *T = nullptr;                 // [Bc][naux^2]
+    double *U = nullptr;                               // [Bc][naux]
+    double *delta = nullptr;                           // [Bc][2]
+    int32_t *items = nullptr;                          // [Bc] items a later step still works on
+};
+
+// G <- X K^-1 X' refined against the fp64 covariance (see kapply_kernel).  On entry the aux rows
+// of the slab hold W = X L^-T and p.dinv every block inverse M_j ([nb0][mstep]).  steps / delta
+// (host, [bc]) receive the per-item step count and last correction; returns the items that did
+// not reach `tol` within `max_steps` in not_refined.
+ngp_status refine_chunk(ngp_ctx *c, const JobGeom &g, const ChunkPtrs &p, const RefineBufs &rb,
+                        double *Gchunk, int bc, size_t mstep, const ngp_spec &spec,
+                        const DevSpec &sp, EventTimer &tm, int32_t *steps, double *delta_out,
+                        std::vector<int> *not_refined) {
+    hipStream_t s = c->stream;
+    const double naux = (double)g.naux, n0 = (double)g.n0;
+    ChunkPtrs pf = p;          // the sweeps are fp64: no shadow rows, no tile maxima
+    pf.L32 = nullptr;
+    pf.tmax = nullptr;
+    pf.mixcnt = nullptr;
+    pf.auxX = nullptr;
+    int na = bc;               // items still being refined (pf.items: their indices; null = all)
+    auto backward = [&](int accumulate) {
+        for (int cc = g.nb0 - 1; cc >= 0; --cc)
+            tm.run(10, na * naux * 2.0 * NB * (double)(cc + 1) * NB,
+                   na * 8.0 * ((double)NB * NB * (cc + 1) + 2.0 * naux * NB * (cc + 1)), [&] {
+                       launch_aux_back(g, pf, p.dinv, mstep, rb.A, accumulate, na, cc, s);
+                   });
+    };
+    backward(0);               // A_0 = W L^-1
+    std::vector<double> dprev((size_t)bc, 1.0), dboth(2 * (size_t)bc, 0.0);
+    std::vector<int32_t> active((size_t)bc);
+    for (int i = 0; i < bc; ++i) { steps[i] = 0; delta_out[i] = 0.0; active[(size_t)i] = i; }
+    for (int it = 1;; ++it) {
+        tm.run(10, na * 2.0 * naux * n0 * n0, na * 8.0 * 3.0 * naux * n0,
+               [&] { launch_kapply(g, pf, rb.A, rb.X, rb.R, na, sp, s); });
+        tm.run(10, na * 4.0 * naux * naux * n0, na * 8.0 * 3.0 * naux * n0, [&] {
+            launch_refine_gram(g, rb.A, rb.X, rb.R, rb.S, rb.T, rb.U, Gchunk, rb.delta, na,
+                               pf.items, s);
+        });
+        HIPCHK(hipMemcpyAsync(dboth.data(), rb.delta, sizeof(double) * 2 * (size_t)bc,
+                              hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int32_t> still;
+        for (int i : active) {
+            const double d = dboth[2 * (size_t)i];
+            // What is left after this step's correction d is about d * rho, rho the contraction
+            // of the iteration: measured as d / d_previous from the second step on, and from the
+            // residual itself (max_a |R_a| / |X_a|) at the first, whichever is larger.
+            double rho = dboth[2 * (size_t)i + 1];
+            if (it > 1) rho = std::max(rho, d / dprev[(size_t)i]);
+            const double est = d * std::min(rho, 1.0);
+            steps[i] = it;
+            delta_out[i] = d;
+            dprev[(size_t)i] = d;
+            if (!(est <= spec.refine_tol)) still.push_back(i);   // NaN stays
+        }
+        active.swap(still);
+        if (active.empty() || it >= spec.refine_max) break;
+        // the next step only touches the items that are not there yet
+        na = (int)active.size();
+        HIPCHK(hipMemcpy(rb.items, active.data(), 4 * (size_t)na, hipMemcpyHostToDevice));
+        pf.items = rb.items;
+        // A += (R L^-T) L^-1: R into the aux rows, forward sweep (the resident-factor kernels),
+        // backward sweep accumulating into A
+        for (int i : active)
+            HIPCHK(hipMemcpyAsync(p.L + (size_t)i * g.item_stride + (size_t)g.n0 * g.ld,
+                                  rb.R + (size_t)i * g.naux_pad * g.n0,
+                                  (size_t)g.naux_pad * g.n0 * 8, hipMemcpyDeviceToDevice, s));
+        for (int jj = 0; jj < g.nb0; ++jj) {
+            ChunkPtrs pj = pf;
+            pj.dinv = p.dinv + (size_t)jj * mstep;
+            tm.run(10, na * naux * (double)NB * NB, na * 8.0 * 3.0 * naux * NB,
+                   [&] { launch_chol_col(g, pj, na, jj, COL_AUX, jj * NB, s); });
+            tm.run(10, na * naux * 2.0 * NB * (double)(g.n0 - (jj + 1) * NB),
+                   na * 8.0 * (g.n0 - (jj + 1) * NB) * (2.0 * naux + NB),
+                   [&] { launch_aux_update(g, pj, na, jj, s); });
+        }
+        backward(1);
+    }
+    for (int i : active) not_refined->push_back(i);
+    return NGP_OK;
+}
+
+}  // namespace
+
 extern "C" ngp_status ngp_job_run(ngp_job *j) {
     if (!j) return NGP_ERR_ARG;
     ngp_ctx *c = j->ctx;
@@ -601,79 +708,120 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     HIPCHK(hipSetDevice(c->device));
     const JobGeom &g = j->g;
     hipStream_t s = c->stream;
-    const DevSpec sp = dev_spec(c->spec);
+    const DevSpec sp = dev_spec(j->spec);
     EventTimer tm(c->profiling, s);
-    EventTimer tm2(c->profiling, c->stream2);
     HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)g.B, s));
     HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
-    void *Lbuf[2] = {nullptr, nullptr}, *dinv[2] = {nullptr, nullptr};
-    void *tab[2] = {nullptr, nullptr}, *sig[2] = {nullptr, nullptr};
-    bool single_chunk = false;
-    auto release_all = [&] {
-        for (int l = 0; l < 2; ++l) {
-            c->release(Lbuf[l]); c->release(dinv[l]); c->release(tab[l]); c->release(sig[l]);
-        }
+    // mixed precision needs at least one fat step (two block columns); shorter series run fp64
+    const bool mixed = j->spec.precision == NGP_PREC_MIXED && g.nb0 >= 2 && !g.aux_identity;
+    const bool refine = mixed && j->spec.refine_max > 0;
+    j->refine_steps.assign((size_t)g.B, 0);
+    j->refine_delta.assign((size_t)g.B, 0.0);
+    j->frac32.assign((size_t)g.B, 0.0);
+    std::vector<void *> bufs;   // everything this run allocates goes back on every exit path
+    struct Releaser {
+        ngp_ctx *c; std::vector<void *> &v;
+        ~Releaser() { for (void *q : v) c->release(q); }
+    } releaser{c, bufs};
+    auto dalloc = [&](void **q, size_t bytes) -> ngp_status {
+        ngp_status st = c->alloc(q, bytes);
+        if (!st) bufs.push_back(*q);
+        return st;
     };
+    void *Lbuf = nullptr, *dinv = nullptr, *tab = nullptr, *sig = nullptr;
+    void *L32 = nullptr, *tmx = nullptr, *cnt = nullptr;
+    RefineBufs rb;
+    bool single_chunk = false;
     if (g.n0 > 0) {
         const size_t tab_bytes = g.lattice ? sizeof(double) * (size_t)g.maxstat * g.R : 0;
         const size_t sig_bytes = g.lattice ? sizeof(double) * (size_t)g.maxcp * g.npts : 0;
-        const size_t item_bytes = (size_t)g.item_stride * sizeof(double) + tab_bytes + sig_bytes;
-        int Bc = (int)std::min<size_t>((size_t)g.B, std::max<size_t>(1, c->mem_cap / item_bytes));
-        // Optional second lane (NGP_LANES=2): each lane owns a slab of half the chunk size and takes
-        // alternate chunks, so chol_diag / fill of one chunk overlap chol_col of the other.
-        // Measured on the headline step: 898-900 ms vs 905-912 ms on one lane (chol_col already
-        // fills the register file), at the price of overlapping per-kernel event timings — so it is
-        // off by default and the roofline figures are always taken on one lane.
-        static const int lanes_env = getenv("NGP_LANES") ? atoi(getenv("NGP_LANES")) : 1;
-        const int nl = (lanes_env >= 2 && g.B >= 4096) ? 2 : 1;
-        if (nl == 2) Bc = std::max(1, std::min(Bc / 2, (g.B + 1) / 2));
-        single_chunk = Bc >= g.B;
         const size_t l_bytes = (size_t)g.item_stride * sizeof(double);
-        ngp_status st = NGP_OK;
-        for (int l = 0; l < nl && !st; ++l) {
-            st = c->alloc(&Lbuf[l], l_bytes * (size_t)Bc);
-            if (!st) st = c->alloc(&dinv[l], sizeof(double) * (size_t)Bc * NB * NB);
-            if (!st && g.lattice) st = c->alloc(&tab[l], tab_bytes * (size_t)Bc);
-            if (!st && g.lattice) st = c->alloc(&sig[l], sig_bytes * (size_t)Bc);
+        const size_t nbt = (size_t)g.nb0 + (size_t)g.naux_pad / NB;
+        const size_t aux_bytes = sizeof(double) * (size_t)g.naux_pad * g.n0;
+        size_t item_bytes = l_bytes + tab_bytes + sig_bytes + sizeof(double) * NB * NB;
+        if (mixed)
+            item_bytes += l_bytes / 2 + 4 * nbt * g.nb0 + aux_bytes +
+                          (refine ? sizeof(double) * NB * NB * (size_t)g.nb0 + 2 * aux_bytes : 0);
+        const int Bc = (int)std::min<size_t>((size_t)g.B, std::max<size_t>(1, c->mem_cap / item_bytes));
+        single_chunk = Bc >= g.B;
+        // refinement sweeps need every block inverse M_j, not only the current one
+        const size_t mstep = refine ? (size_t)Bc * NB * NB : 0;
+        ngp_status st = dalloc(&Lbuf, l_bytes * (size_t)Bc);
+        if (!st) st = dalloc(&dinv, sizeof(double) * (size_t)Bc * NB * NB * (refine ? g.nb0 : 1));
+        if (!st && g.lattice) st = dalloc(&tab, tab_bytes * (size_t)Bc);
+        if (!st && g.lattice) st = dalloc(&sig, sig_bytes * (size_t)Bc);
+        if (!st && mixed) {
+            st = dalloc(&L32, (l_bytes / 2) * (size_t)Bc);
+            if (!st) st = dalloc(&tmx, 4 * nbt * g.nb0 * (size_t)Bc);
+            if (!st) st = dalloc(&cnt, 8 * (size_t)Bc);
+            if (!st) st = dalloc((void **)&rb.X, aux_bytes * (size_t)Bc);
         }
-        if (st) { release_all(); return st; }
-        if (nl == 2) {   // lane 2 starts after the memsets queued on lane 1
-            (void)hipEventRecord(c->ev_lane2, s);
-            (void)hipStreamWaitEvent(c->stream2, c->ev_lane2, 0);
+        if (!st && refine) {
+            st = dalloc((void **)&rb.A, aux_bytes * (size_t)Bc);
+            if (!st) st = dalloc((void **)&rb.R, aux_bytes * (size_t)Bc);
+            if (!st) st = dalloc((void **)&rb.S, 8 * (size_t)g.naux * g.naux * Bc);
+            if (!st) st = dalloc((void **)&rb.T, 8 * (size_t)g.naux * g.naux * Bc);
+            if (!st) st = dalloc((void **)&rb.U, 8 * (size_t)g.naux * Bc);
+            if (!st) st = dalloc((void **)&rb.delta, 16 * (size_t)Bc);
+            if (!st) st = dalloc((void **)&rb.items, 4 * (size_t)Bc);
         }
+        if (st) return st;
+        const Lane ln = lane_of(c);
         const double nrows_aux = (double)g.naux;
-        int chunk = 0;
-        for (int b0 = 0; b0 < g.B; b0 += Bc, ++chunk) {
+        for (int b0 = 0; b0 < g.B; b0 += Bc) {
             const int bc = std::min(Bc, g.B - b0);
-            const int l = chunk % nl;
-            const Lane ln = lane_of(c, l);
-            EventTimer &t = l ? tm2 : tm;
             ChunkPtrs p{};
-            p.L = (double *)Lbuf[l];
-            p.dinv = (double *)dinv[l];
+            p.L = (double *)Lbuf;
+            p.dinv = (double *)dinv;
             p.progs = j->progs + b0;
             p.t0 = j->t0;
             p.taux = j->taux;
             p.y0 = j->y0 + (g.y_shared ? 0 : (int64_t)b0 * g.n0);
             p.logdet = j->logdet + b0;
             p.info = j->info + b0;
-            p.tab = (double *)tab[l];
-            p.sig = (double *)sig[l];
+            p.tab = (double *)tab;
+            p.sig = (double *)sig;
             p.qpts = j->qpts;
+            if (mixed) {
+                p.L32 = (float *)L32;
+                p.tmax = (float *)tmx;
+                p.mixcnt = (unsigned *)cnt;
+                p.auxX = rb.X;
+                HIPCHK(hipMemsetAsync(cnt, 0, 8 * (size_t)bc, s));
+            }
             if (g.lattice)
-                t.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, ln.main); });
+                tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
             const double fill_elems =
                 (double)bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0);
-            t.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, ln.main); });
-            factor_chunk(ln, g, p, bc, t);
-            t.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0, [&] {
-                launch_gram(g, (const double *)Lbuf[l], j->G + (int64_t)b0 * g.naux * g.naux, bc,
-                            ln.main);
-            });
-        }
-        if (nl == 2) {   // join lane 2 before the epilogue
-            (void)hipEventRecord(c->ev_lane2, c->stream2);
-            (void)hipStreamWaitEvent(s, c->ev_lane2, 0);
+            tm.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, s); });
+            factor_chunk(ln, g, p, bc, tm, mstep, mixed ? &sp : nullptr);
+            double *Gchunk = j->G + (int64_t)b0 * g.naux * g.naux;
+            tm.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0,
+                   [&] { launch_gram(g, (const double *)Lbuf, Gchunk, bc, s); });
+            if (mixed) {
+                std::vector<unsigned> hc(2 * (size_t)bc);
+                HIPCHK(hipMemcpyAsync(hc.data(), cnt, 8 * (size_t)bc, hipMemcpyDeviceToHost, s));
+                std::vector<int> bad;
+                if (refine) {
+                    ngp_status rs = refine_chunk(c, g, p, rb, Gchunk, bc, mstep, j->spec, sp, tm,
+                                                 j->refine_steps.data() + b0,
+                                                 j->refine_delta.data() + b0, &bad);
+                    if (rs) { tm.resolve(c->prof); return rs; }
+                } else {
+                    HIPCHK(hipStreamSynchronize(s));
+                }
+                for (int i = 0; i < bc; ++i) {
+                    const double a = hc[2 * (size_t)i], b = hc[2 * (size_t)i + 1];
+                    j->frac32[(size_t)(b0 + i)] = (a + b) > 0.0 ? a / (a + b) : 0.0;
+                }
+                if (!bad.empty()) {   // keep a pivot failure if the factorisation reported one
+                    std::vector<int32_t> hi((size_t)bc);
+                    HIPCHK(hipMemcpy(hi.data(), p.info, 4 * (size_t)bc, hipMemcpyDeviceToHost));
+                    for (int i : bad)
+                        if (hi[(size_t)i] == 0) hi[(size_t)i] = NGP_INFO_NOT_REFINED;
+                    HIPCHK(hipMemcpy(p.info, hi.data(), 4 * (size_t)bc, hipMemcpyHostToDevice));
+                }
+            }
         }
     }
     EpiPtrs e{};
@@ -691,18 +839,28 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     e.sigma = j->sigma;
     e.work_stride = j->work_stride;
     if (g.lattice && single_chunk) {   // the tables of the only chunk are still in place
-        e.tab = (const double *)tab[0];
-        e.sig = (const double *)sig[0];
+        e.tab = (const double *)tab;
+        e.sig = (const double *)sig;
         e.qpts = j->qpts;
     }
     tm.run(3, 0.0, 0.0, [&] { launch_epilogue(g, e, sp, s); });
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipGetLastError();
     tm.resolve(c->prof);
-    tm2.resolve(c->prof);
-    release_all();
     if (err != hipSuccess) return (ngp_status)err;
     j->ran = true;
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_job_mixed_stats(ngp_job *j, int32_t *refine_steps, double *refine_delta,
+                                          double *frac_f32) {
+    if (!j) return NGP_ERR_ARG;
+    if (!j->ran) return NGP_ERR_STATE;
+    for (int i = 0; i < j->g.B; ++i) {
+        if (refine_steps) refine_steps[i] = j->refine_steps[(size_t)i];
+        if (refine_delta) refine_delta[i] = j->refine_delta[(size_t)i];
+        if (frac_f32) frac_f32[i] = j->frac32[(size_t)i];
+    }
     return NGP_OK;
 }
 
@@ -833,6 +991,7 @@ struct ngp_factor {
     int32_t *info = nullptr;              // [P]
     std::vector<double> logml0;
     std::vector<int32_t> info0;
+    ngp_spec spec{};                      // the spec the factor was created under (always fp64)
 };
 
 namespace {
@@ -845,7 +1004,8 @@ ngp_status factor_run(ngp_factor *f, ngp_job *j, bool create) {
     JobGeom &g = j->g;
     g.item_stride = f->item_stride;
     hipStream_t s = c->stream;
-    const DevSpec sp = dev_spec(c->spec);
+    j->spec = f->spec;
+    const DevSpec sp = dev_spec(f->spec);
     EventTimer tm(c->profiling, s);
     const int P = f->P;
     void *tab = nullptr, *sig = nullptr;
@@ -879,7 +1039,7 @@ ngp_status factor_run(ngp_factor *f, ngp_job *j, bool create) {
             HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)P, s));
             tm.run(4, 0.0, 8.0 * P * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0),
                    [&] { launch_fill(g, p, P, sp, s); });
-            factor_chunk(lane_of(c, 0), g, p, P, tm, mstep);
+            factor_chunk(lane_of(c), g, p, P, tm, mstep);
             HIPCHK(hipMemcpyAsync(f->logdet, j->logdet, sizeof(double) * (size_t)P,
                                   hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemcpyAsync(f->info, j->info, sizeof(int32_t) * (size_t)P,
@@ -952,6 +1112,8 @@ extern "C" ngp_status ngp_factor_create(ngp_ctx *c, int32_t P, const ngp_kernel 
     f->ctx = c;
     f->P = P;
     f->n = n;
+    (void)ngp_get_spec(c, &f->spec);
+    f->spec.precision = NGP_PREC_F64;     // a resident factor is queried many times: keep it exact
     f->ldy = ldy ? n : 0;
     f->ops.resize((size_t)P);
     f->params.resize((size_t)P);
@@ -1202,7 +1364,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
         tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + (double)g.naux * g.n0),
                [&] { launch_fill(g, p, bc, sp, s); });
-        factor_chunk(lane_of(c, 0), g, p, bc, tm);
+        factor_chunk(lane_of(c), g, p, bc, tm);
         const double n3 = (double)g.n0 * g.n0 * g.n0;
         tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
             launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
@@ -1317,9 +1479,8 @@ extern "C" ngp_status ngp_microbench_mfma_f64(ngp_ctx *c, int32_t iters, double 
     void *out = nullptr;
     ngp_status st = c->alloc(&out, sizeof(double) * (size_t)blocks * 256);
     if (st) return st;
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
+    struct Rel { ngp_ctx *c; void *p; ~Rel() { c->release(p); } } rel{c, out};
+    ScopedEvent a, b;
     launch_mfma_bench((double *)out, iters, blocks, c->stream);  // warm-up
     HIPCHK(hipEventRecord(a, c->stream));
     launch_mfma_bench((double *)out, iters, blocks, c->stream);
@@ -1327,9 +1488,6 @@ extern "C" ngp_status ngp_microbench_mfma_f64(ngp_ctx *c, int32_t iters, double 
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    c->release(out);
     *tflops = (double)blocks * 4.0 * (double)iters * 2048.0 / ((double)ms * 1e-3) * 1e-12;
     return NGP_OK;
 }
@@ -1347,9 +1505,8 @@ extern "C" ngp_status ngp_microbench_mfma_f64_detail(ngp_ctx *c, int32_t iters,
     void *st = nullptr;
     ngp_status s0 = c->alloc(&st, sizeof(unsigned long long) * 2 * (size_t)waves);
     if (s0) return s0;
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
+    struct Rel { ngp_ctx *c; void *p; ~Rel() { c->release(p); } } rel{c, st};
+    ScopedEvent a, b;
     launch_mfma_bench_detail((unsigned long long *)st, iters, blocks, c->stream);
     HIPCHK(hipEventRecord(a, c->stream));
     launch_mfma_bench_detail((unsigned long long *)st, iters, blocks, c->stream);
@@ -1360,9 +1517,6 @@ extern "C" ngp_status ngp_microbench_mfma_f64_detail(ngp_ctx *c, int32_t iters,
     HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    c->release(st);
     std::vector<double> cyc((size_t)waves), ghz((size_t)waves);
     for (int w = 0; w < waves; ++w) {
         cyc[(size_t)w] = (double)h[2 * (size_t)w] / (double)iters;
@@ -1388,10 +1542,8 @@ extern "C" ngp_status ngp_microbench_hbm(ngp_ctx *c, int64_t bytes, double *writ
     if (st) return st;
     st = c->alloc(&b, (size_t)n * 8);
     if (st) { c->release(a); return st; }
-    hipEvent_t e0, e1, e2;
-    HIPCHK(hipEventCreate(&e0));
-    HIPCHK(hipEventCreate(&e1));
-    HIPCHK(hipEventCreate(&e2));
+    struct Rel { ngp_ctx *c; void *p, *q; ~Rel() { c->release(p); c->release(q); } } rel{c, a, b};
+    ScopedEvent e0, e1, e2;
     launch_stream_write((double *)a, n, c->stream);
     launch_stream_copy((double *)b, (const double *)a, n, c->stream);
     HIPCHK(hipEventRecord(e0, c->stream));
@@ -1403,8 +1555,6 @@ extern "C" ngp_status ngp_microbench_hbm(ngp_ctx *c, int64_t bytes, double *writ
     float w = 0.f, cp = 0.f;
     HIPCHK(hipEventElapsedTime(&w, e0, e1));
     HIPCHK(hipEventElapsedTime(&cp, e1, e2));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
-    c->release(a); c->release(b);
     if (write_gbs) *write_gbs = (double)n * 8.0 / ((double)w * 1e-3) * 1e-9;
     if (copy_gbs) *copy_gbs = 2.0 * (double)n * 8.0 / ((double)cp * 1e-3) * 1e-9;
     return NGP_OK;
@@ -1432,6 +1582,31 @@ extern "C" ngp_status ngp_selftest_mfma_layout(ngp_ctx *c, const double *A, cons
     if (e == hipSuccess) {
         launch_mfma_layout_probe((const double *)da, (const double *)db, (double *)dd, c->stream);
         e = hipMemcpyAsync(D, dd, 512 * 8, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    c->release(da); c->release(db); c->release(dd);
+    return e == hipSuccess ? NGP_OK : (ngp_status)e;
+}
+
+// D (32 x 32, row-major) = A (32 x 2) B (2 x 32) through one v_mfma_f32_32x32x2_f32 with the operand
+// and result maps the mixed-precision k-loop assumes; the caller compares with A @ B.
+extern "C" ngp_status ngp_selftest_mfma_f32_layout(ngp_ctx *c, const float *A, const float *Bm,
+                                                   float *D) {
+    if (!c || !A || !Bm || !D) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    void *da = nullptr, *db = nullptr, *dd = nullptr;
+    ngp_status st;
+    if ((st = c->alloc(&da, 64 * 4)) || (st = c->alloc(&db, 64 * 4)) ||
+        (st = c->alloc(&dd, 1024 * 4))) {
+        c->release(da); c->release(db); c->release(dd);
+        return st;
+    }
+    hipError_t e = hipMemcpyAsync(da, A, 64 * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db, Bm, 64 * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_mfma_f32_probe((const float *)da, (const float *)db, (float *)dd, c->stream);
+        e = hipMemcpyAsync(D, dd, 1024 * 4, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     c->release(da); c->release(db); c->release(dd);

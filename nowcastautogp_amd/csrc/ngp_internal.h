@@ -31,8 +31,9 @@ struct DevProgram {
 static_assert(sizeof(DevProgram) % 8 == 0, "DevProgram is copied as 8-byte words");
 
 struct DevSpec {
-    int32_t se_form, periodic_form, cp_form, pad;
+    int32_t se_form, periodic_form, cp_form, precision;
     double  jitter;
+    double  mixed_tau;   // NGP_PREC_MIXED: see ngp_spec in include/ngp.h
 };
 
 // Geometry of one staged job on the device (all items share times; see ngp_api.hip).
@@ -76,6 +77,15 @@ struct ChunkPtrs {
     const int32_t *qpts;  // [npts] lattice coordinate of every point (t0 then taux)
     double       *dtab;   // [Bc][maxstat][3][R] gradient jobs on a lattice: per stationary leaf the
                           // unscaled factor e and the two parameter-derivative factors (else null)
+    // ---- NGP_PREC_MIXED jobs only (all null otherwise) ----
+    float        *L32;    // [Bc][item_stride] fp32 shadow of the finished off-diagonal tiles of L
+                          // and of the aux rows W (operands of the fp32 tile products)
+    float        *tmax;   // [Bc][nb0 + naux_pad/64][nb0] max |.| of every finished 64x64 tile
+                          // (row tile, block column); aux tiles follow the nb0 main row tiles
+    unsigned     *mixcnt; // [Bc][2] tile products of the fat steps that ran in fp32 / in fp64
+    double       *auxX;   // [Bc][naux_pad][n0] the fill also leaves the aux rows X here
+    const int32_t *items; // refinement sweeps: the items (indices into the chunk) a launch works
+                          // on, Bc = their count; null: all of them in order
 };
 
 struct EpiPtrs {
@@ -104,8 +114,22 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
                  bool aux_only = false);
 void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int k0, hipStream_t s);
 enum { COL_FULL = 0, COL_FAT = 1, COL_THIN = 2, COL_AUX = 3 };
+// sp: only mixed_tau / jitter are read, and only when p.L32 is set (mixed-precision job)
 void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mode, int k0,
-                     hipStream_t s);
+                     hipStream_t s, const DevSpec *sp = nullptr);
+// ---- Gram refinement of NGP_PREC_MIXED (G = X K^-1 X' against the fp64 covariance) ----
+// A_c = C_c L_cc^-1, then C_j -= A_c L_(c,j) for j < c, c descending: C (aux rows of the slab,
+// [Bc][naux_pad][n0] at rows n0.. of p.L) becomes C (L L')^-1 ... see aux_back_kernel
+void launch_aux_back(const JobGeom &g, const ChunkPtrs &p, const double *dinv_all, size_t mstep,
+                     double *Aout, int accumulate, int Bc, int c, hipStream_t s);
+// R = X - A K  (K re-evaluated tile by tile from the kernel trees / lattice tables)
+void launch_kapply(const JobGeom &g, const ChunkPtrs &p, const double *A, const double *X,
+                   double *R, int Bc, const DevSpec &sp, hipStream_t s);
+// G = sym(A X' + R A'); delta[2b] = max |R A'| relative to sqrt(G_aa G_bb), delta[2b+1] = max_a |R_a|/|X_a|
+void launch_refine_gram(const JobGeom &g, const double *A, const double *X, const double *R,
+                        double *S, double *T, double *U, double *G, double *delta, int Bc,
+                        const int32_t *items, hipStream_t s);
+void launch_mfma_f32_probe(const float *A, const float *Bm, float *Dout, hipStream_t s);
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,

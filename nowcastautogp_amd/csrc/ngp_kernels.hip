@@ -30,8 +30,6 @@
 //   D: lane l, register r holds D[m = (l>>4) + 4 r][n = l&15]
 // so a D-layout tile is directly the B operand of a following product that sums over its row
 // index (register r <-> k-slot), which is what keeps the triangular solve in registers.
-#include <cstdlib>
-
 #include "ngp_internal.h"
 
 namespace ngp {
@@ -275,6 +273,8 @@ __global__ __launch_bounds__(256) void fill_kernel(JobGeom g, ChunkPtrs p, int n
             }
         }
         *reinterpret_cast<f64x2 *>(Lit + row * g.ld + col) = v;
+        if (aux && p.auxX)   // mixed-precision jobs keep the untouched aux rows X for the refinement
+            *reinterpret_cast<f64x2 *>(p.auxX + ((long)item * g.naux_pad + (row - g.n0)) * g.ld + col) = v;
     }
 }
 
@@ -466,6 +466,8 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
             }
         }
         *reinterpret_cast<f64x2 *>(Lit + row * g.ld + col) = v;
+        if (aux && p.auxX)   // mixed-precision jobs keep the untouched aux rows X for the refinement
+            *reinterpret_cast<f64x2 *>(p.auxX + ((long)item * g.naux_pad + (row - g.n0)) * g.ld + col) = v;
     }
 }
 
@@ -847,9 +849,15 @@ __device__ __forceinline__ void stage_mstrips(double *lds_m, const double *mstri
     }
 }
 
+// SHADOW (mixed-precision jobs): every finished row also goes out rounded to fp32 (Lr32, same
+// indexing) and the largest magnitude of the tile to *tmax_out — the fat steps of later columns
+// decide from those maxima which tile products may run on the fp32 matrix cores.
+template <bool SHADOW = false>
 __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], double *Lr,
                                                     const double *lds_m, long ld, int kmax,
-                                                    int lane, double *buf, int dbg = 0) {
+                                                    int lane, double *buf, float *Lr32 = nullptr,
+                                                    float *tmax_out = nullptr) {
+    double amax = 0.0;
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;          // row of S' inside a 16-tile
 #pragma unroll
@@ -860,13 +868,8 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * it + ((n16 + 4 * r) & 15);
-                const double kv = (dbg & 8) ? 1.0 : Lr[(long)i * ld + kmax + 16 * jt + jj0];
-                c4[jt][r] = kv - acc4[jt][it][r];
+                c4[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0] - acc4[jt][it][r];
             }
-        if (dbg & 16) {   // timing ablation: no M C' product
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) buf[n16 * EPI_PITCH + 16 * jt + isub] = c4[jt][0] + c4[jt][1] + c4[jt][2] + c4[jt][3];
-        } else
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {            // output rows 16 ct ..: C' tiles jt <= ct
 #pragma unroll
@@ -894,10 +897,23 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
         for (int w = 0; w < 8; ++w) {
             const int idx = w * 64 + lane, row = idx >> 5, cp = idx & 31;
             const f64x2 v = *reinterpret_cast<const f64x2 *>(buf + row * EPI_PITCH + 2 * cp);
-            if (!(dbg & 32) || (v.x == 1.2345e-300))
-                *reinterpret_cast<f64x2 *>(Lr + (long)(16 * it + row) * ld + kmax + 2 * cp) = v;
+            *reinterpret_cast<f64x2 *>(Lr + (long)(16 * it + row) * ld + kmax + 2 * cp) = v;
+            if constexpr (SHADOW) {
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 vf;
+                vf.x = (float)v.x;
+                vf.y = (float)v.y;
+                *reinterpret_cast<f32x2 *>(Lr32 + (long)(16 * it + row) * ld + kmax + 2 * cp) = vf;
+                amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (SHADOW) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+        // rounded UP to fp32: the decision must never see a maximum smaller than the true one
+        if (lane == 0) *tmax_out = __double2float_ru(amax);
     }
 }
 
@@ -923,20 +939,27 @@ struct ColStep {
     int nmain;    // main row tiles below the diagonal (r = j+1 ...); 0: aux tiles only
     int ntiles;   // nmain + aux tiles
     int groups;   // workgroups per item
-    int dbg;      // timing ablations of the fat kernel (results wrong when != 0): 1 no restaging,
-                  // 2 no barriers, 4 no epilogue, 8 no K-tile reads, 16 no M C' product, 32 no row
-                  // stores; from the NGP_ABLATE environment variable only, never through the API
+    // mixed-precision jobs: a tile product runs in fp32 iff max|A| max|B| <= c32 (noise + jitter),
+    // c32 = mixed_tau / (64 * 2^-24)
+    double c32, jitter;
 };
+// index of a finished tile's maximum in ChunkPtrs::tmax (per item): row tiles 0..nb0-1 are the
+// main block rows, nb0.. the aux tiles
+__device__ __forceinline__ long tmax_index(const JobGeom &g, int row_tile, int col) {
+    return (long)row_tile * g.nb0 + col;
+}
 
 // THIN and FULL steps: direct operand loads (short k-loops), one row tile per wave.
+template <bool MIXED>
 __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                           ColStep st) {
     __shared__ __attribute__((aligned(16))) char epi[EPI_LDS_BYTES];
     const int wg = blockIdx.x;
     const int xcd = wg & 7, idx = wg >> 3;   // blocks b and b+8 share an XCD (speed only)
-    const int item = (idx / st.groups) * 8 + xcd;
+    const int slot = (idx / st.groups) * 8 + xcd;
     const int grp = idx % st.groups;
-    if (item >= Bc) return;                  // whole workgroup, before any barrier
+    if (slot >= Bc) return;                  // whole workgroup, before any barrier
+    const int item = p.items ? p.items[slot] : slot;   // refinement sweeps: compacted item list
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tile = grp * 4 + wave;             // row tile
@@ -977,8 +1000,17 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     stage_mstrips(reinterpret_cast<double *>(epi), p.dinv + (long)item * (NB * NB), tid);
     __syncthreads();
     if (!valid) return;
-    solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
-                        reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES));
+    if constexpr (MIXED) {
+        const int rt = (tile < st.nmain) ? j + 1 + tile : g.nb0 + (tile - st.nmain);
+        solve_and_store_lds<true>(
+            acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
+            reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES),
+            p.L32 + (long)item * g.item_stride + rowbase * ld,
+            p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
+    } else {
+        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
+                            reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES));
+    }
 }
 
 constexpr int LDS_KC = 16;   // k-depth of one staged chunk
@@ -1003,6 +1035,22 @@ constexpr int LDS_KC = 16;   // k-depth of one staged chunk
 // address register — which also keeps hipcc from fusing the reads into ds_read2_b64 (banked
 // mod 32, inherently 2-way conflicting on 16-byte-granular layouts).
 // ---------------------------------------------------------------------------------------
+//
+// MIXED (NGP_PREC_MIXED jobs, BASELINE config C5).  The k-range of a step is cut into 64-wide
+// k-tiles; a k-tile runs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, operands from the
+// fp32 shadow L32, twice the fp64 rate and half the bytes) iff for all four operand tiles of the
+// workgroup   max|A| max|B| <= c32 (noise + jitter)   — then the rounding error of that product,
+// 64 * 2^-24 * max|A| max|B|, stays below mixed_tau of the smallest pivot the matrix can have
+// (every pivot of K + (noise + jitter) I is >= noise + jitter).  All other k-tiles, the
+// accumulators, the K tile, the solve and the stored factor are fp64.  The fp32 k-tiles go first
+// into 64 fp32 accumulators, which are handed to the fp64 accumulators through LDS (one
+// transposition of the 32x32 C/D layout into the 4x4x4 composite layout), then the fp64 k-tiles
+// follow on top: one accumulator set is live at a time.  Same LDS image for both passes: a staged
+// chunk is 128 B per row — 16 doubles or 32 floats.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool MIXED>
 __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                                ColStep st) {
     // 32 LDS-DMA blocks (8 rows x 128 B) per buffer, each followed by a 128-B gap: row groups of
@@ -1034,7 +1082,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     // tiles of a workgroup share the staged k-range, so it starts at the smaller of their starts;
     // a workgroup whose tiles are all still zero leaves before the first barrier.
     int kbeg = st.k0;
-    if (g.aux_identity && tile0 >= st.nmain) {
+    if (!MIXED && g.aux_identity && tile0 >= st.nmain) {
         // workgroup-uniform: first k of each of the two tiles (kmax + 1: nothing to do)
         int kfirst = kmax + 1;
 #pragma unroll
@@ -1103,32 +1151,225 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
 
-    const int nchunks = (kmax - kbeg) / LDS_KC;
-    if (nchunks > 0) {
-        stage(0, kbeg);
-        __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-        for (int c = 0; c < nchunks; ++c) {
-            const int cur = c & 1;
-            if (c + 1 < nchunks && !(st.dbg & 1)) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
-            const char *buf = smem + cur * STAGE;
+    // one 16-deep fp64 chunk in buffer `buf`: 256 mfma4 per wave
+    auto mult64 = [&](const char *buf) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                double a[4];
+        for (int s = 0; s < 4; ++s) {
+            double a[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 2 * BLKB);
+            for (int u = 0; u < 4; ++u)
+                a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 2 * BLKB);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    Rot4 br;
-                    br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 2 * BLKB);
-                    br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 2 * BLKB);
-                    br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * 2 * BLKB);
-                    br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * 2 * BLKB);
+            for (int it = 0; it < 4; ++it) {
+                Rot4 br;
+                br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 2 * BLKB);
+                br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 2 * BLKB);
+                br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * 2 * BLKB);
+                br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * 2 * BLKB);
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[jt], br);
+                for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[jt], br);
+            }
+        }
+    };
+
+    if constexpr (!MIXED) {
+        const int nchunks = (kmax - kbeg) / LDS_KC;
+        if (nchunks > 0) {
+            stage(0, kbeg);
+            __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
+            for (int c = 0; c < nchunks; ++c) {
+                const int cur = c & 1;
+                if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
+                mult64(smem + cur * STAGE);
+                __syncthreads();
+            }
+        }
+    } else {
+        // ---- which k-tiles may run in fp32 (workgroup-uniform; every wave evaluates it) ----
+        const int nkt = j;                          // k-tiles 0 .. j-1 (<= 128)
+        const int nbt = g.nb0 + g.naux_pad / NB;
+        const float *tm = p.tmax + (long)item * nbt * g.nb0;
+        const int t1 = min(tile0 + 1, st.ntiles - 1);
+        const int rt0 = (tile0 < st.nmain) ? j + 1 + tile0 : g.nb0 + (tile0 - st.nmain);
+        const int rt1 = (t1 < st.nmain) ? j + 1 + t1 : g.nb0 + (t1 - st.nmain);
+        const double lim = st.c32 * (p.progs[item].noise + st.jitter);
+        unsigned long long m32lo, m32hi;
+        {
+            bool c[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kt = lane + 64 * h;
+                c[h] = false;
+                if (kt < nkt) {
+                    const float ta = fmaxf(tm[tmax_index(g, j, kt)], tm[tmax_index(g, j + 1, kt)]);
+                    const float tb = fmaxf(tm[tmax_index(g, rt0, kt)], tm[tmax_index(g, rt1, kt)]);
+                    c[h] = (double)ta * (double)tb <= lim;
                 }
             }
-            if (!(st.dbg & 2)) __syncthreads();
+            m32lo = __ballot(c[0]);
+            m32hi = __ballot(c[1]);
+        }
+        const unsigned long long inlo = nkt >= 64 ? ~0ull : ((1ull << nkt) - 1ull);
+        const unsigned long long inhi = nkt <= 64 ? 0ull : (nkt >= 128 ? ~0ull : ((1ull << (nkt - 64)) - 1ull));
+        unsigned long long m64lo = inlo & ~m32lo, m64hi = inhi & ~m32hi;
+        const int n32 = __popcll(m32lo) + __popcll(m32hi);
+        const int n64 = __popcll(m64lo) + __popcll(m64hi);
+        if (tid == 0 && p.mixcnt) {
+            const unsigned nv = (unsigned)(2 * min(2, st.ntiles - tile0));   // wave tiles that count
+            atomicAdd(p.mixcnt + 2 * item, nv * (unsigned)n32);
+            atomicAdd(p.mixcnt + 2 * item + 1, nv * (unsigned)n64);
+        }
+        auto pop = [](unsigned long long &lo, unsigned long long &hi) -> int {
+            if (lo) {
+                const int b = __builtin_ctzll(lo);
+                lo &= lo - 1;
+                return b;
+            }
+            const int b = __builtin_ctzll(hi);
+            hi &= hi - 1;
+            return 64 + b;
+        };
+
+        if (n32 > 0) {
+            // ---- fp32 pass: 32-deep chunks of the shadow rows, v_mfma_f32_32x32x2_f32 ----
+            const __amdgpu_buffer_rsrc_t rsrc32 = __builtin_amdgcn_make_buffer_rsrc(
+                p.L32 + (long)item * g.item_stride, 0, (int)(g.item_stride * (long)sizeof(float)),
+                0x00020000);
+            const unsigned soff32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(src_row0 * ld * 4));
+            const unsigned row_step32 = (unsigned)(8 * ld * 4);
+            const unsigned v32_even = (unsigned)((lane >> 3) * ld * 4 + 16 * ((lane & 7) ^ ((lane >> 4) & 7)));
+            const unsigned v32_odd = (unsigned)((lane >> 3) * ld * 4 + 16 * ((lane & 7) ^ ((4 + (lane >> 4)) & 7)));
+            auto stage32 = [&](int buf, int k) {
+                const unsigned kb = (unsigned)k * 4u;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    lds_ptr dst = (lds_ptr)(smem + buf * STAGE + (8 * wave + i) * BLKB);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc32, dst, 16,
+                                                             (i & 1) ? v32_odd : v32_even,
+                                                             soff32 + i * row_step32 + kb, 0, 0);
+                }
+            };
+            // lane (r32 = lane & 31, h = lane >> 5) holds rows r32 of its two A and two B blocks; of
+            // the 32 k-values of a chunk it reads pieces 2u + h (k = 8u + 4h .. + 3), u = 0..3, and
+            // feeds element e of piece u to MFMA step (u, e): both operands use the same k-map
+            const int r32 = lane & 31, h = lane >> 5;
+            unsigned a32[2][4], b32[2][4];
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int arow = 64 * col + 32 * blk + r32;
+                const int brow = 128 + 64 * ltile + 32 * blk + r32;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a32[blk][u] = (unsigned)(row_off(arow) + (((2 * u + h) ^ ((arow >> 1) & 7)) << 4));
+                    b32[blk][u] = (unsigned)(row_off(brow) + (((2 * u + h) ^ ((brow >> 1) & 7)) << 4));
+                }
+            }
+            // two-level accumulation: the fp32 accumulators carry ONE k-tile (32 MFMA steps) and are
+            // then added into fp64 partial sums of the same 32x32 layout.  Left in fp32 across all
+            // k-tiles, the accumulator itself grows to the size of K (its rounding error, 2^-24 of
+            // THAT, is what broke pivots at n >= 4096 — profiles/r02/README.md).
+            f32x16 acc32[2][2];
+            double acc64p[2][2][16];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        acc32[a][b][v] = 0.f;
+                        acc64p[a][b][v] = 0.0;
+                    }
+            unsigned long long lo = m32lo, hi = m32hi;
+            const int nch = 2 * n32;
+            int kt_cur = pop(lo, hi), sub = 1;
+            stage32(0, kt_cur * NB);
+            __syncthreads();
+            for (int c = 0; c < nch; ++c) {
+                const int cur = c & 1;
+                if (c + 1 < nch) {
+                    if (sub == 2) {
+                        kt_cur = pop(lo, hi);
+                        sub = 0;
+                    }
+                    stage32(cur ^ 1, kt_cur * NB + 32 * sub);
+                    ++sub;
+                }
+                const char *buf = smem + cur * STAGE;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    f32x4 av[2], bv[2];
+#pragma unroll
+                    for (int blk = 0; blk < 2; ++blk) {
+                        av[blk] = *reinterpret_cast<const f32x4 *>(buf + a32[blk][u]);
+                        bv[blk] = *reinterpret_cast<const f32x4 *>(buf + b32[blk][u]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int b = 0; b < 2; ++b)
+                                acc32[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    av[a][e], bv[b][e], acc32[a][b], 0, 0, 0);
+                }
+                if (c & 1) {   // a k-tile is two chunks: its sum moves to the fp64 level
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) {
+                                acc64p[a][b][v] += (double)acc32[a][b][v];
+                                acc32[a][b][v] = 0.f;
+                            }
+                }
+                __syncthreads();
+            }
+            // ---- hand-over: D[m = 32a + (v&3) + 8(v>>2) + 4h][n = 32b + r32] of the 32x32 layout
+            //      -> LDS tile [jj = m][i = n] (per wave, 32 rows at a time, pitch 65 doubles)
+            //      -> acc4[jt][it][r]
+            constexpr int P64 = 65;
+            double *t64 = reinterpret_cast<double *>(smem) + wave * (32 * P64);
+            static_assert(4 * 32 * P64 * 8 <= 2 * STAGE, "hand-over tiles must fit the stage buffers");
+            const int jj0 = 4 * (r16 >> 2) + q;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        t64[((v & 3) + 8 * (v >> 2) + 4 * h) * P64 + 32 * b + r32] = acc64p[a][b][v];
+                __syncthreads();
+#pragma unroll
+                for (int jl = 0; jl < 2; ++jl)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc4[2 * a + jl][it][r] =
+                                t64[(16 * jl + jj0) * P64 + 16 * it + ((r16 + 4 * r) & 15)];
+                __syncthreads();   // before the next half / the fp64 pass overwrites the tiles
+            }
+        }
+        if (n64 > 0) {
+            unsigned long long lo = m64lo, hi = m64hi;
+            const int nch = 4 * n64;
+            int kt_cur = pop(lo, hi), sub = 1;
+            stage(0, kt_cur * NB);
+            __syncthreads();
+            for (int c = 0; c < nch; ++c) {
+                const int cur = c & 1;
+                if (c + 1 < nch) {
+                    if (sub == 4) {
+                        kt_cur = pop(lo, hi);
+                        sub = 0;
+                    }
+                    stage(cur ^ 1, kt_cur * NB + LDS_KC * sub);
+                    ++sub;
+                }
+                mult64(smem + cur * STAGE);
+                __syncthreads();
+            }
         }
     }
     // the staging buffers are free (every wave passed the k-loop's last barrier): M strips go to
@@ -1137,25 +1378,20 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     stage_mstrips(reinterpret_cast<double *>(smem), p.dinv + (long)item * (NB * NB), tid);
     __syncthreads();
     if (!valid) return;
-    if (st.dbg & 4) {   // timing ablation: keep the accumulators alive, skip the epilogue
-        double sum = 0.0;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sum += acc4[a][b][r];
-        if (sum == 1.2345e-300) p.logdet[item] = sum;
-        return;
-    }
 
     double *Lr = Lit + tile_row0(tile) * ld;
     if (col) {
         subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane);
+    } else if constexpr (MIXED) {
+        const int rt = (tile < st.nmain) ? j + 1 + tile : g.nb0 + (tile - st.nmain);
+        solve_and_store_lds<true>(
+            acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
+            reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES),
+            p.L32 + (long)item * g.item_stride + tile_row0(tile) * ld,
+            p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
     } else {
         solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
-                            reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES),
-                            st.dbg);
+                            reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES));
     }
 }
 
@@ -1183,7 +1419,7 @@ __global__ __launch_bounds__(64, 2) void diag_ahead_kernel(JobGeom g, ChunkPtrs 
 // long k-loop on a single wave per aux tile:  W_j = C_j M_j' (chol_col_kernel, empty k-range),
 // then this kernel:  C_c -= W_j L_(c,j)'  for every block column c > j, one wave per (aux tile, c).
 __global__ __launch_bounds__(256, 2) void aux_update_kernel(JobGeom g, ChunkPtrs p, int j) {
-    const int item = blockIdx.y;
+    const int item = p.items ? p.items[blockIdx.y] : blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntl = g.naux_pad / NB;
@@ -1205,6 +1441,234 @@ __global__ __launch_bounds__(256, 2) void aux_update_kernel(JobGeom g, ChunkPtrs
     gemm_rows<4>(acc4, Lc + (long)r16 * ld + 2 * q, Wa + (long)r16 * ld + 2 * q, ld, j * NB,
                  (j + 1) * NB);
     subtract_in_place_perm(Wa, ld, c * NB, acc4, lane);
+}
+
+// ---------------------------------------------------------------------------------------
+// Gram refinement of NGP_PREC_MIXED jobs.  X = the aux rows as filled ([k(t_aux, t0) ; y']), P = L L'
+// the mixed-precision factor, K the exact fp64 covariance.  With A ~ X K^-1:
+//     R = X - A K                      (kapply_kernel: K re-evaluated tile by tile, never stored)
+//     G = A X' + R A'                  (refine_gram_*: second-order accurate in the error of A)
+//     A += (R L^-T) L^-1               (forward sweep = the resident-factor kernels; backward sweep
+//                                       = aux_back_kernel)
+// A_0 = W L^-1 from the W = X L^-T the factorisation leaves in the aux rows.
+// ---------------------------------------------------------------------------------------
+// position of M[R][C] inside the strip-ordered block inverse chol_diag writes
+__device__ __forceinline__ int mstrip_index(int R, int C) {
+    return (((R >> 2) * 4 + (C >> 4)) << 6) + (R & 3) + 4 * ((C >> 2) & 3) + 16 * (C & 3);
+}
+
+// items of the chunk a refinement launch works on: all of them, or the compacted list of those
+// that have not converged yet
+__device__ __forceinline__ int map_item(const ChunkPtrs &p, int i) {
+    return p.items ? p.items[i] : i;
+}
+
+// Backward sweep, block column c (c descending across launches), two launches per block column:
+//   aux_back_solve_kernel   A_c = C_c L_cc^-1 = C_c M_c, in place in the aux rows and out to Aout
+//                           ([Bc][naux_pad][n0]; accumulate: +=); one workgroup per (aux tile, item)
+//   aux_back_update_kernel  C_b -= A_c L_(c,b) for every b < c; one wave per (aux tile, b), the same
+//                           4x4x4 MFMA tile product as the forward sweep with the L tile read
+//                           transposed (k runs down its rows)
+__global__ __launch_bounds__(256) void aux_back_solve_kernel(JobGeom g, ChunkPtrs p,
+                                                             const double *Mc, double *Aout,
+                                                             int accumulate, int c) {
+    __shared__ double Ms[NB][NB + 1];   // M = L_cc^-1, natural layout
+    __shared__ double Cs[NB][NB + 1];   // the aux tile's block column c
+    const int item = map_item(p, blockIdx.y), at = blockIdx.x, tid = threadIdx.x;
+    const long ld = g.ld;
+    double *Caux = p.L + (long)item * g.item_stride + ((long)g.n0 + (long)at * NB) * ld + c * NB;
+    const double *M = Mc + (long)item * (NB * NB);
+    const int rows = min(NB, g.naux - at * NB);
+    for (int e = tid; e < NB * NB; e += 256) {
+        const int i = e >> 6, jj = e & 63;
+        Ms[i][jj] = (i >= jj) ? M[mstrip_index(i, jj)] : 0.0;
+        Cs[i][jj] = (i < rows) ? Caux[(long)i * ld + jj] : 0.0;
+    }
+    __syncthreads();
+    const int jc = tid & 63, w = tid >> 6;
+    for (int a = w; a < rows; a += 4) {
+        double sum = 0.0;
+        for (int i = jc; i < NB; ++i) sum += Cs[a][i] * Ms[i][jc];
+        Caux[(long)a * ld + jc] = sum;
+        double *dst = Aout + ((long)item * g.naux_pad + at * NB + a) * ld + c * NB + jc;
+        *dst = accumulate ? *dst + sum : sum;
+    }
+}
+
+// 8 k-values of four 16-row fragments of a TRANSPOSED operand: element (m, k) lives at p[k * ld + m]
+// (lane (r16, q): rows m = 16 u + r16, k = 2 q, 2 q + 1)
+__device__ __forceinline__ void load_frag8_t(Frag8<4> &f, const double *p, long ld) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        f.v[u].x = p[16 * u];
+        f.v[u].y = p[ld + 16 * u];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void aux_back_update_kernel(JobGeom g, ChunkPtrs p, int c) {
+    const int item = map_item(p, blockIdx.y);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntl = (g.naux + NB - 1) / NB;          // aux tiles that hold real rows
+    const int idx = blockIdx.x * 4 + wave;
+    if (idx >= ntl * c) return;
+    const int at = idx % ntl, b = idx / ntl;
+    const long ld = g.ld;
+    double *Lit = p.L + (long)item * g.item_stride;
+    double *Wa = Lit + ((long)g.n0 + (long)at * NB) * ld;          // aux tile rows (B operand)
+    const double *Lcb = Lit + (long)c * NB * ld + (long)b * NB;    // L tile (c, b), A operand^T
+    const int r16 = lane & 15, q = lane >> 4;
+    double acc4[4][4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[x][y][r] = 0.0;
+    // S'[jj][a] = sum_k L[64 c + k][64 b + jj] A_c[a][k]
+    const double *pa = Lcb + (long)(2 * q) * ld + r16;
+    const double *pb = Wa + (long)r16 * ld + c * NB + 2 * q;
+    Frag8<4> a[3], bb[3];             // 8-deep stages, two of them in flight ahead of the MFMAs
+    load_frag8_t(a[0], pa, ld);
+    load_frag8(bb[0], pb, ld);
+    load_frag8_t(a[1], pa + 8 * ld, ld);
+    load_frag8(bb[1], pb + 8, ld);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s + 2 < 8) {
+            load_frag8_t(a[(s + 2) % 3], pa + (long)(8 * (s + 2)) * ld, ld);
+            load_frag8(bb[(s + 2) % 3], pb + 8 * (s + 2), ld);
+        }
+        mfma_frag8(acc4, a[s % 3], bb[s % 3]);
+    }
+    subtract_in_place_perm(Wa, ld, b * NB, acc4, lane);
+}
+
+// R[:, col] = X[:, col] - sum_row A[:, row] K[row][col]: one thread per column, the rows of A it
+// multiplies are wave-uniform (LDS broadcast), K comes from the lattice tables (or the direct
+// interpreter) element by element and is never stored.  One workgroup per (256 columns, item, aux
+// tile); rows are walked in slabs of KA_ROWS so that a slab of A sits in LDS.
+constexpr int KA_ROWS = NB;   // n0 is a multiple of NB: every slab is whole
+template <int NACC>
+__global__ __launch_bounds__(256) void kapply_kernel(JobGeom g, ChunkPtrs p, const double *A,
+                                                     const double *X, double *Rout, DevSpec sp) {
+    __shared__ DevProgram P;
+    __shared__ double As[NACC][KA_ROWS];
+    const int item = map_item(p, blockIdx.y), tid = threadIdx.x;
+    const int a0 = blockIdx.z * NACC;
+    const int rows = min(NACC, g.naux - a0);
+    if (rows <= 0) return;
+    load_program(&P, p.progs + item);
+    __syncthreads();
+    const long ld = g.ld;
+    const double *Ai = A + ((long)item * g.naux_pad + a0) * ld;
+    const double *Xi = X + ((long)item * g.naux_pad + a0) * ld;
+    double *Ri = Rout + ((long)item * g.naux_pad + a0) * ld;
+    const double *tab = g.lattice ? p.tab + (long)item * g.maxstat * g.R : nullptr;
+    const double *sig = g.lattice ? p.sig + (long)item * g.maxcp * g.npts : nullptr;
+    const int col = blockIdx.x * 256 + tid;          // n0 is a multiple of 64, the grid of 256
+    const bool live = col < g.n0;
+    const int colc = live ? col : g.n0 - 1;
+    const double t2 = p.t0[colc];
+    const int q2 = g.lattice ? p.qpts[colc] : 0;
+    const double diag = P.noise + sp.jitter;
+    double acc[NACC];
+#pragma unroll
+    for (int s = 0; s < NACC; ++s) acc[s] = 0.0;
+    for (int r0 = 0; r0 < g.n0; r0 += KA_ROWS) {
+        __syncthreads();
+        for (int e = tid; e < NACC * KA_ROWS; e += 256) {
+            const int a = e / KA_ROWS, rr = e % KA_ROWS;
+            As[a][rr] = (a < rows) ? Ai[(long)a * ld + r0 + rr] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int rr = 0; rr < KA_ROWS; ++rr) {
+            const int row = r0 + rr;
+            const double t1 = p.t0[row];
+            double v = g.lattice ? keval_lattice(P, tab, sig, g.R, g.npts, t1, t2,
+                                                 abs(p.qpts[row] - q2), row, colc)
+                                 : keval(P, sp, t1, t2);
+            if (row == colc) v += diag;
+            if (row >= g.n_real || colc >= g.n_real) v = (row == colc) ? 1.0 : 0.0;
+#pragma unroll
+            for (int s = 0; s < NACC; ++s) acc[s] += As[s][rr] * v;
+        }
+    }
+    if (live)
+        for (int s = 0; s < rows; ++s) Ri[(long)s * ld + col] = Xi[(long)s * ld + col] - acc[s];
+}
+
+// S[a][b] = A_a . X_b + R_a . A_b and T[a][b] = R_a . A_b for all naux^2 pairs, one wave per pair
+__global__ __launch_bounds__(256) void refine_gram_pairs_kernel(JobGeom g, const double *A,
+                                                                const double *X, const double *R,
+                                                                double *S, double *T, double *U,
+                                                                const int32_t *items) {
+    const int item = items ? items[blockIdx.y] : blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pr = blockIdx.x * 4 + wave;
+    if (pr >= g.naux * g.naux) return;
+    const int a = pr / g.naux, b = pr % g.naux;
+    const long base = (long)item * g.naux_pad * g.ld;
+    const double *Aa = A + base + (long)a * g.ld, *Ab = A + base + (long)b * g.ld;
+    const double *Xb = X + base + (long)b * g.ld, *Ra = R + base + (long)a * g.ld;
+    double s0 = 0.0, t0 = 0.0, rr = 0.0, xx = 0.0;
+    for (int k = lane; k < g.n0; k += 64) {
+        s0 += Aa[k] * Xb[k];
+        t0 += Ra[k] * Ab[k];
+        if (a == b) {   // wave-uniform: |R_a|^2 and |X_a|^2 for the contraction estimate
+            rr += Ra[k] * Ra[k];
+            xx += Xb[k] * Xb[k];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        t0 += __shfl_down(t0, off, 64);
+        rr += __shfl_down(rr, off, 64);
+        xx += __shfl_down(xx, off, 64);
+    }
+    if (lane == 0) {
+        S[(long)item * g.naux * g.naux + pr] = s0 + t0;
+        T[(long)item * g.naux * g.naux + pr] = t0;
+        if (a == b) U[(long)item * g.naux + a] = xx > 0.0 ? rr / xx : 0.0;
+    }
+}
+
+// G = (S + S') / 2;  delta[2 item] = max |T + T'| / 2 relative to sqrt(G_aa G_bb), the size of the
+// correction this step applied;  delta[2 item + 1] = max_a |R_a| / |X_a|, how far (L L')^-1 K is
+// from the identity along the rows of X (the factor by which the next correction is smaller)
+__global__ __launch_bounds__(256) void refine_gram_final_kernel(JobGeom g, const double *S,
+                                                                const double *T, const double *U,
+                                                                double *G, double *delta,
+                                                                const int32_t *items) {
+    __shared__ double red[256];
+    const int item = items ? items[blockIdx.x] : blockIdx.x;
+    const int tid = threadIdx.x, na = g.naux;
+    const double *Si = S + (long)item * na * na, *Ti = T + (long)item * na * na;
+    double *Gi = G + (long)item * na * na;
+    double dm = 0.0;
+    for (int e = tid; e < na * na; e += 256) {
+        const int a = e / na, b = e % na;
+        Gi[e] = 0.5 * (Si[a * na + b] + Si[b * na + a]);
+        const double gaa = Si[a * na + a], gbb = Si[b * na + b];
+        const double den = sqrt(fabs(gaa * gbb));
+        const double tv = 0.5 * fabs(Ti[a * na + b] + Ti[b * na + a]);
+        if (den > 0.0) dm = fmax(dm, tv / den);
+        else if (tv > 0.0) dm = INFINITY;
+    }
+    red[tid] = dm;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        delta[2 * item] = red[0];
+        double rho2 = 0.0;
+        for (int a = 0; a < na; ++a) rho2 = fmax(rho2, U[(long)item * na + a]);
+        delta[2 * item + 1] = sqrt(rho2);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1966,6 +2430,20 @@ __global__ void mfma4_composite_probe_kernel(const double *A, const double *Bm, 
     for (int r = 0; r < 4; ++r) Dout[((l >> 4) + 4 * r) * 16 + (l & 15)] = d[r];
 }
 
+// D[32x32] = A[32x2] B[2x32] through one v_mfma_f32_32x32x2_f32 with the operand / result maps
+// the mixed-precision k-loop assumes
+__global__ void mfma_f32_probe_kernel(const float *A, const float *Bm, float *Dout) {
+    const int l = threadIdx.x;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(l & 31) * 2 + (l >> 5)], Bm[(l >> 5) * 32 + (l & 31)],
+                                               acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+        Dout[((v & 3) + 8 * (v >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[v];
+}
+
 __global__ __launch_bounds__(256) void stream_write_kernel(f64x2 *dst, long n2) {
     const f64x2 v = {1.0, 2.0};
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256)
@@ -2005,10 +2483,13 @@ void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int k
 }
 
 void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mode, int k0,
-                     hipStream_t s) {
+                     hipStream_t s, const DevSpec *sp) {
     ColStep st{};
-    static const int dbg = getenv("NGP_ABLATE") ? atoi(getenv("NGP_ABLATE")) : 0;
-    st.dbg = dbg;
+    const bool mixed = p.L32 != nullptr && sp != nullptr;
+    if (mixed) {
+        st.c32 = sp->mixed_tau / (64.0 * 5.9604644775390625e-08);   // 64 * 2^-24
+        st.jitter = sp->jitter;
+    }
     st.j = j;
     st.k0 = k0;
     st.nmain = (mode == COL_AUX) ? 0 : g.nb0 - 1 - j;
@@ -2017,13 +2498,49 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
     const int bpad = (Bc + 7) / 8 * 8;
     if (mode == COL_FAT) {
         st.groups = (st.ntiles + 1) / 2;
-        hipLaunchKernelGGL(chol_col_glds_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p, Bc,
-                           st);
+        if (mixed)
+            hipLaunchKernelGGL(chol_col_glds_kernel<true>, dim3(st.groups * bpad), dim3(256), 0, s,
+                               g, p, Bc, st);
+        else
+            hipLaunchKernelGGL(chol_col_glds_kernel<false>, dim3(st.groups * bpad), dim3(256), 0, s,
+                               g, p, Bc, st);
     } else {
         st.groups = (st.ntiles + 3) / 4;
-        hipLaunchKernelGGL(chol_col_kernel, dim3(st.groups * bpad), dim3(256), 0, s, g, p,
-                           Bc, st);
+        if (mixed)
+            hipLaunchKernelGGL(chol_col_kernel<true>, dim3(st.groups * bpad), dim3(256), 0, s, g, p,
+                               Bc, st);
+        else
+            hipLaunchKernelGGL(chol_col_kernel<false>, dim3(st.groups * bpad), dim3(256), 0, s, g,
+                               p, Bc, st);
     }
+}
+
+void launch_aux_back(const JobGeom &g, const ChunkPtrs &p, const double *dinv_all, size_t mstep,
+                     double *Aout, int accumulate, int Bc, int c, hipStream_t s) {
+    const int ntl = (g.naux + NB - 1) / NB;
+    hipLaunchKernelGGL(aux_back_solve_kernel, dim3(ntl, Bc), dim3(256), 0, s, g, p,
+                       dinv_all + (size_t)c * mstep, Aout, accumulate, c);
+    if (c > 0)
+        hipLaunchKernelGGL(aux_back_update_kernel, dim3((ntl * c + 3) / 4, Bc), dim3(256), 0, s, g,
+                           p, c);
+}
+
+void launch_kapply(const JobGeom &g, const ChunkPtrs &p, const double *A, const double *X,
+                   double *R, int Bc, const DevSpec &sp, hipStream_t s) {
+    // accumulators per thread: 16 aux rows at a time (the usual d + m + 1 <= 16 is one pass)
+    constexpr int NACC = 16;
+    hipLaunchKernelGGL(kapply_kernel<NACC>, dim3((g.n0 + 255) / 256, Bc, (g.naux + NACC - 1) / NACC),
+                       dim3(256), 0, s, g, p, A, X, R, sp);
+}
+
+void launch_refine_gram(const JobGeom &g, const double *A, const double *X, const double *R,
+                        double *S, double *T, double *U, double *G, double *delta, int Bc,
+                        const int32_t *items, hipStream_t s) {
+    const int npairs = g.naux * g.naux;
+    hipLaunchKernelGGL(refine_gram_pairs_kernel, dim3((npairs + 3) / 4, Bc), dim3(256), 0, s, g, A,
+                       X, R, S, T, U, items);
+    hipLaunchKernelGGL(refine_gram_final_kernel, dim3(Bc), dim3(256), 0, s, g, (const double *)S,
+                       (const double *)T, (const double *)U, G, delta, items);
 }
 
 void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {
@@ -2098,6 +2615,9 @@ void launch_mfma_bench_detail(unsigned long long *stamps, int iters, int blocks,
 void launch_mfma_layout_probe(const double *A, const double *Bm, double *Dout, hipStream_t s) {
     hipLaunchKernelGGL(mfma_layout_probe_kernel, dim3(1), dim3(64), 0, s, A, Bm, Dout);
     hipLaunchKernelGGL(mfma4_composite_probe_kernel, dim3(1), dim3(64), 0, s, A, Bm, Dout + 256);
+}
+void launch_mfma_f32_probe(const float *A, const float *Bm, float *Dout, hipStream_t s) {
+    hipLaunchKernelGGL(mfma_f32_probe_kernel, dim3(1), dim3(64), 0, s, A, Bm, Dout);
 }
 void launch_stream_write(double *dst, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(stream_write_kernel, dim3(2048), dim3(256), 0, s,

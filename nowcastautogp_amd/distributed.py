@@ -1,7 +1,7 @@
 """Multi-GPU layout of the path: particles are block-partitioned over ranks (one process per
 GPU); every (particle, scenario) evaluation is rank-local.  The ONLY exchange step is the
 particle log-weight normalisation / resampling of ``maybe_resample!`` (reference
-src/forecasting.jl:251-254): an all-gather of P doubles per scenario (2 KiB at P = 256) —
+src/forecasting.jl:138-141): an all-gather of P doubles per scenario (2 KiB at P = 256) —
 latency-bound, one collective per weight update, never per item.  Backend: ``torch.distributed``
 ("nccl" is RCCL over xGMI on ROCm; "gloo" in the CPU tests).
 """

@@ -1,6 +1,6 @@
 """The two call sites of the hot path, mirrored: ``make_and_fit_model`` (reference
-src/make_and_fit_model.jl:98-113) and ``forecast`` / ``forecast_with_nowcasts`` (reference
-src/forecasting.jl:142-280), plus the small containers their signatures need (``TData``,
+src/make_and_fit_model.jl:78-93) and ``forecast`` / ``forecast_with_nowcasts`` (reference
+src/forecasting.jl:29-167), plus the small containers their signatures need (``TData``,
 ``create_transformed_data``, ``create_nowcast_data``: reference src/TData.jl:46-74,
 src/create_nowcast_data.jl:27-76).  Same names, argument meaning and error behaviour, so the
 reference's shape / assertion tests read the same against this module (tests/test_mirror_*.py).
@@ -64,7 +64,7 @@ def create_nowcast_data(nowcasts, dates, *, transformation: Callable = lambda y:
 
 def _stabilize_for_fit(y, *, flat_threshold: float = 1.0e-3, rng=None):
     """Jitter a near-constant series so the GP covariance stays positive definite (reference
-    src/make_and_fit_model.jl:37-47)."""
+    src/make_and_fit_model.jl:17-27)."""
     y = np.asarray(y, dtype=np.float64)
     n = y.size
     if n <= 1:
@@ -103,7 +103,7 @@ def make_and_fit_model(data: TData, *, n_particles: int = 1, smc_data_proportion
 
 
 def _apply(inv_transformation: Callable, a: np.ndarray) -> np.ndarray:
-    """Elementwise ``inv_transformation.(a)`` (reference src/forecasting.jl:161).  Callables that
+    """Elementwise ``inv_transformation.(a)`` (reference src/forecasting.jl:48).  Callables that
     already map arrays elementwise (identity, ``np.exp``, Box-Cox inverses) are applied in one go;
     scalar-only ones (``math.exp``, branches on the value) go through ``np.vectorize``."""
     try:
@@ -118,7 +118,7 @@ def _apply(inv_transformation: Callable, a: np.ndarray) -> np.ndarray:
 def forecast(model: GPModel, forecast_dates, forecast_draws: int, *,
              inv_transformation: Callable = lambda y: y,
              forecast_n_hmc: Optional[int] = None) -> np.ndarray:
-    """Matrix (len(forecast_dates), forecast_draws) of samples (reference src/forecasting.jl:142-188)."""
+    """Matrix (len(forecast_dates), forecast_draws) of samples (reference src/forecasting.jl:29-75)."""
     dates = list(forecast_dates)
     if forecast_n_hmc is None:
         draws = autogp.predict_mvn(model, dates).rand(int(forecast_draws))
@@ -166,7 +166,7 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
 
 def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transformation,
                                     ess_threshold):
-    """All scenarios in one engine call: one factorisation per particle (src/forecasting.jl:246-268
+    """All scenarios in one engine call: one factorisation per particle (src/forecasting.jl:133-155
     with n_mcmc = n_hmc = 0)."""
     t, y = model._obs()
     t_add = model.ds_transform.apply(autogp.to_days(list(nowcasts[0].ds)))

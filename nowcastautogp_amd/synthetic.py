@@ -90,7 +90,7 @@ def make_workload(name: str = "C3", n: int | None = None, P: int | None = None,
 
 def jitter_programs(programs, copies: int, rng: np.random.Generator, rel: float = 0.02):
     """``copies`` perturbed versions of every program (distinct-K mode of the bench: stands in
-    for the per-draw HMC-refined parameters of forecast_n_hmc, reference src/forecasting.jl:176-181).
+    for the per-draw HMC-refined parameters of forecast_n_hmc, reference src/forecasting.jl:63-68).
     Layout: item = p * copies + c."""
     out = []
     for ops, params, noise in programs:

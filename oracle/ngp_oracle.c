@@ -22,16 +22,16 @@
  *        docs/src/vignettes/setting-priors.md:229-236 (numbering),
  *        SURVEY.md Appendix B (formulas, [RECALLED]).
  *   ngpo_logml     the per-particle evaluation behind fit_smc!/add_data!
- *        (src/make_and_fit_model.jl:111, src/forecasting.jl:248):
+ *        (src/make_and_fit_model.jl:91, src/forecasting.jl:135):
  *        logml = -1/2 y'K^-1 y - sum log L_ii - n/2 log 2pi, K = k(t,t)+(noise+jitter)I.
  *   ngpo_predict   the per-particle conditional MVN behind predict_mvn
- *        (src/forecasting.jl:159,179): mu = K21 K11^-1 y, S = K22 - K21 K11^-1 K12.
+ *        (src/forecasting.jl:46,66): mu = K21 K11^-1 y, S = K22 - K21 K11^-1 K12.
  *   ngpo_nowcast   one scenario task of forecast_with_nowcasts with
- *        n_mcmc = n_hmc = 0 (src/forecasting.jl:246-268), done the way the
+ *        n_mcmc = n_hmc = 0 (src/forecasting.jl:133-155), done the way the
  *        reference does it: an independent full factorisation at n+d per scenario.
- *   ngpo_weights_normalize   maybe_resample! arithmetic (src/forecasting.jl:251-254).
+ *   ngpo_weights_normalize   maybe_resample! arithmetic (src/forecasting.jl:138-141).
  *   ngpo_logml_grad   d logml / d theta = 1/2 tr((aa' - K^-1) dK/dtheta), the quantity
- *        HMC needs inside mcmc_parameters! (src/forecasting.jl:178,261).
+ *        HMC needs inside mcmc_parameters! (src/forecasting.jl:65,148).
  */
 #include "ngp_oracle.h"
 
@@ -442,6 +442,10 @@ void ngpo_default_spec(ngp_spec *s) {
     s->se_form = 0;
     s->periodic_form = 0;
     s->cp_form = 0;
+    s->precision = 0;
+    s->mixed_tau = 1e-5;
+    s->refine_tol = 1e-9;
+    s->refine_max = 3;
     s->reserved = 0;
     s->jitter = 1e-5;
 }

@@ -9,8 +9,8 @@ fixtures, tests/test_oracle.py) is the parity anchor available.
 
 It is also the CPU baseline of ``bench.py``: the same LAPACK family Julia's LinearAlgebra uses
 (OpenBLAS ``dpotrf``/``dpotrs``), run the way the reference runs it — BLAS threads = 1
-(src/forecasting.jl:114-123) and one worker thread per host core over (particle, scenario)
-items (src/forecasting.jl:244-245).
+(src/forecasting.jl:1-10) and one worker thread per host core over (particle, scenario)
+items (src/forecasting.jl:131-132).
 """
 from __future__ import annotations
 
@@ -195,7 +195,7 @@ def weights_normalize(logw):
 
 
 # ---------------------------------------------------------------------------------------------
-# mixture sampling (include/ngp.h ngp_mixture_sample; reference src/forecasting.jl:160,180 draws
+# mixture sampling (include/ngp.h ngp_mixture_sample; reference src/forecasting.jl:47,67 draws
 # with Julia's RNG, which nothing here can reproduce — this restates the LIBRARY's stream)
 # ---------------------------------------------------------------------------------------------
 def philox4x32_10(ctr, key):

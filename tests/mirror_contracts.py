@@ -130,7 +130,7 @@ def check_forecast_with_nowcasts(engine):
                                   days(11, 12), 3, inv_transformation=math.exp)
     assert r.shape == (1, 3) and (r > 0).all()              # :175-177
     assert nc.forecast_with_nowcasts(base, multi, days(12, 16), 3).shape == (4, 6)   # :222
-    # the base model is never mutated (src/forecasting.jl:214)
+    # the base model is never mutated (src/forecasting.jl:101)
     after = base.to_dict()
     assert after["n_obs"] == before["n_obs"] and np.array_equal(after["y"], before["y"])
     assert after["particles"] == before["particles"]
@@ -167,7 +167,7 @@ def check_batched_nowcast_equals_per_scenario_updates(engine):
 
 
 def check_snapshot_round_trip(engine):
-    # Dict(model) / GPModel(dict): src/forecasting.jl:241,246; deepcopy-able pure data
+    # Dict(model) / GPModel(dict): src/forecasting.jl:128,133; deepcopy-able pure data
     import copy
     model = fitted(engine, seed=9, n_particles=2)
     d = copy.deepcopy(model.to_dict())
