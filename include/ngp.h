@@ -80,7 +80,7 @@ typedef struct ngp_spec {
      * A += (X - A K) (L L')^-1) until the predicted remaining relative error is below
      * refine_tol or refine_max steps were taken; an item that does not get there is
      * reported with info = NGP_INFO_NOT_REFINED.  log det comes from the factor itself.   */
-    double  mixed_tau;     /* default 1e-5                                              */
+    double  mixed_tau;     /* default 1e-6                                              */
     double  refine_tol;    /* default 1e-9                                              */
     int32_t refine_max;    /* default 3 (0: no refinement)                              */
     int32_t reserved;

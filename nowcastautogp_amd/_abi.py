@@ -61,7 +61,7 @@ class NgpProfile(C.Structure):
 def default_spec(precision: int = NGP_PREC_F64) -> NgpSpec:
     """The library defaults (``ngp_default_spec``), optionally with the mixed-precision
     factorisation of BASELINE config C5 switched on."""
-    return NgpSpec(0, 0, 0, int(precision), 1e-5, 1e-5, 1e-9, 3, 0)
+    return NgpSpec(0, 0, 0, int(precision), 1e-5, 1e-6, 1e-9, 3, 0)
 
 
 def as_f64(a) -> np.ndarray:

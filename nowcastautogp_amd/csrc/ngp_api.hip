@@ -230,7 +230,7 @@ extern "C" void ngp_default_spec(ngp_spec *s) {
     s->cp_form = 0;
     s->precision = NGP_PREC_F64;
     s->jitter = 1e-5;
-    s->mixed_tau = 1e-5;
+    s->mixed_tau = 1e-6;
     s->refine_tol = 1e-9;
     s->refine_max = 3;
     s->reserved = 0;

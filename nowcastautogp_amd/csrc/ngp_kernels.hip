@@ -1395,10 +1395,16 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     }
 }
 
-// diag-ahead: K_(j+2,j+2) -= L_(j+2),[0,kmax) L_(j+2),[0,kmax)' — one wave per item, next to the
-// fat launch (pre-accumulates the next-but-one diagonal tile so chol_diag's own k-loop is <= 128)
-__global__ __launch_bounds__(64, 2) void diag_ahead_kernel(JobGeom g, ChunkPtrs p, int j) {
+// diag-ahead: K_(j+2,j+2) -= L_(j+2),[0,kmax) L_(j+2),[0,kmax)' — one workgroup per item, next to
+// the fat launch (pre-accumulates the next-but-one diagonal tile so chol_diag's own k-loop is
+// <= 128).  NW waves split the k-range and add their partial tiles in wave order through LDS: with
+// few items and a long history (64 particles at n = 8192) a single wave per item took 0.8 ms per
+// launch and the main stream waited for it at every second block column.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void diag_ahead_kernel(JobGeom g, ChunkPtrs p, int j) {
+    __shared__ double part[NW > 1 ? 64 * 64 : 1];   // [register][lane]: conflict-free
     const int item = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long ld = g.ld;
     double *Ld = p.L + (long)item * g.item_stride + (long)(j + 2) * NB * ld;
     const int r16 = lane & 15, q = lane >> 4;
@@ -1410,7 +1416,33 @@ __global__ __launch_bounds__(64, 2) void diag_ahead_kernel(JobGeom g, ChunkPtrs 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
     const double *pd = Ld + (long)r16 * ld + 2 * q;
-    gemm_rows<4>(acc4, pd, pd, ld, 0, j * NB);
+    // k-range in NW pieces, each a multiple of 16 (gemm_rows' stage depth)
+    const int kmax = j * NB, per = ((kmax / 16 + NW - 1) / NW) * 16;
+    const int k0 = min(wave * per, kmax), k1 = min(k0 + per, kmax);
+    gemm_rows<4>(acc4, pd, pd, ld, k0, k1);
+    if constexpr (NW > 1) {
+        for (int w = 1; w < NW; ++w) {          // wave w adds its tile; wave 0 collects last
+            if (wave == w) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            double *e = &part[((a * 4 + b) * 4 + r) * 64 + lane];
+                            *e = (w == 1) ? acc4[a][b][r] : *e + acc4[a][b][r];
+                        }
+            }
+            __syncthreads();
+        }
+        if (wave != 0) return;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc4[a][b][r] += part[((a * 4 + b) * 4 + r) * 64 + lane];
+    }
     subtract_in_place_perm(Ld, ld, (j + 2) * NB, acc4, lane);
 }
 
@@ -2550,7 +2582,12 @@ void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipS
 }
 
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {
-    hipLaunchKernelGGL(diag_ahead_kernel, dim3(Bc), dim3(64), 0, s, g, p, j);
+    // the split depends on the geometry only (not on the batch), so a given matrix is always
+    // summed in the same order
+    if (j * NB >= 2048)
+        hipLaunchKernelGGL(diag_ahead_kernel<4>, dim3(Bc), dim3(256), 0, s, g, p, j);
+    else
+        hipLaunchKernelGGL(diag_ahead_kernel<1>, dim3(Bc), dim3(64), 0, s, g, p, j);
 }
 
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,

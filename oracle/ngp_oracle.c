@@ -443,7 +443,7 @@ void ngpo_default_spec(ngp_spec *s) {
     s->periodic_form = 0;
     s->cp_form = 0;
     s->precision = 0;
-    s->mixed_tau = 1e-5;
+    s->mixed_tau = 1e-6;
     s->refine_tol = 1e-9;
     s->refine_max = 3;
     s->reserved = 0;
