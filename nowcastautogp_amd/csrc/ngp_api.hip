@@ -66,7 +66,7 @@ struct TNode {
 // commute bit-exactly in IEEE arithmetic; ChangePoint gets a swapped-operand opcode.
 // perm[device param index] = caller's param index.
 ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int> *perm,
-                           int *n_stat = nullptr, int *n_cp = nullptr) {
+                           int *n_stat = nullptr, int *n_cp = nullptr, int *n_tab = nullptr) {
     ngp_status st = check_program(k);
     if (st) return st;
     std::vector<TNode> nodes;
@@ -94,11 +94,12 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
     if (perm) perm->clear();
     // iterative post-order with child reordering
     struct Frame { int node, stage; };
-    std::vector<int> dev_index(nodes.size(), -1);
+    std::vector<int> dev_index(nodes.size(), -1), dev_first(nodes.size(), -1);
     std::vector<Frame> fs{{stack.back(), 0}};
     while (!fs.empty()) {
         Frame &f = fs.back();
         const TNode &nd = nodes[f.node];
+        if (dev_first[(size_t)f.node] < 0) dev_first[(size_t)f.node] = no;   // first op of its subtree
         const bool swap = nd.op >= NGP_OP_PLUS && nodes[nd.right].need > nodes[nd.left].need;
         if (nd.op < NGP_OP_PLUS || f.stage == 2) {
             int op = nd.op;
@@ -125,6 +126,55 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
     }
     if (n_stat) *n_stat = nstat;
     if (n_cp) *n_cp = ncp;
+    // ---- reduced program: maximal stationary subtrees become table leaves ----
+    std::vector<char> stat(nodes.size(), 0);
+    for (size_t i = 0; i < nodes.size(); ++i) {   // postfix input order: children come first
+        const TNode &nd = nodes[i];
+        if (nd.op == NGP_OP_PLUS || nd.op == NGP_OP_TIMES)
+            stat[i] = stat[(size_t)nd.left] && stat[(size_t)nd.right];
+        else
+            stat[i] = nd.op != NGP_OP_LINEAR && nd.op != NGP_OP_CHANGEPOINT;
+    }
+    int nr = 0, ntab = 0;
+    struct RFrame { int node, stage; };
+    std::vector<RFrame> rs{{stack.back(), 0}};
+    while (!rs.empty()) {
+        RFrame &f = rs.back();
+        const TNode &nd = nodes[(size_t)f.node];
+        const int di = dev_index[(size_t)f.node];
+        if (stat[(size_t)f.node]) {
+            out->rops[nr] = (uint8_t)OP_TABLE;
+            out->rslot[nr] = (uint8_t)ntab;
+            out->tb_first[ntab] = (uint8_t)dev_first[(size_t)f.node];
+            out->tb_last[ntab] = (uint8_t)di;
+            ++ntab;
+            ++nr;
+            rs.pop_back();
+        } else if (nd.op < NGP_OP_PLUS) {   // Linear
+            out->rops[nr] = (uint8_t)nd.op;
+            out->rpoff[nr] = out->poff[di];
+            ++nr;
+            rs.pop_back();
+        } else {
+            const bool swap = nodes[(size_t)nd.right].need > nodes[(size_t)nd.left].need;
+            if (f.stage == 0) {
+                f.stage = 1;
+                rs.push_back({swap ? nd.right : nd.left, 0});
+            } else if (f.stage == 1) {
+                f.stage = 2;
+                rs.push_back({swap ? nd.left : nd.right, 0});
+            } else {
+                out->rops[nr] = out->ops[di];       // Plus / Times / ChangePoint or its swapped form
+                out->rslot[nr] = out->slot[di];
+                out->rpoff[nr] = out->poff[di];
+                ++nr;
+                rs.pop_back();
+            }
+        }
+    }
+    out->n_rops = nr;
+    out->n_tab = ntab;
+    if (n_tab) *n_tab = ntab;
     return NGP_OK;
 }
 
@@ -497,10 +547,10 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     std::vector<DevProgram> hp((size_t)P);
     int maxstat = 0, maxcp = 0;
     for (int i = 0; i < P; ++i) {
-        int ns = 0, nc = 0;
-        ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], nullptr, &ns, &nc);
+        int ns = 0, nc = 0, nt = 0;
+        ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], nullptr, &ns, &nc, &nt);
         if (st) return st;
-        maxstat = std::max(maxstat, ns);
+        maxstat = std::max(maxstat, nt);   // value job: one table per maximal stationary subtree
         maxcp = std::max(maxcp, nc);
     }
     JobGeom g{};

@@ -15,6 +15,10 @@ constexpr int DEV_STACK = 8;  // register-resident evaluation stack depth on the
 // device opcode = host opcode, plus CP with its two operands in swapped stack order
 // (the host reorders children so the evaluation stack never exceeds DEV_STACK)
 constexpr int OP_CP_SWAPPED = 9;
+// reduced program only: a whole stationary subtree (no Linear, no ChangePoint below it) read from
+// its table by lattice distance
+constexpr int OP_TABLE = 10;
+constexpr int MAX_TABLES = NGP_MAX_OPS / 2;   // a tree of NGP_MAX_OPS nodes has at most that many leaves
 
 // One particle's kernel, flattened for the device.  Copied into LDS by every workgroup that
 // needs it; ops are uniform across the workgroup so the interpreter never diverges.
@@ -27,6 +31,15 @@ struct DevProgram {
     uint8_t first[NGP_MAX_OPS];  // binary ops: index of the operand evaluated first (the second is i-1)
     uint8_t poff[NGP_MAX_OPS];   // per op: offset of its parameters in params[]
     double  params[NGP_MAX_PARAMS];
+    // Reduced program for value jobs on lattice times: every maximal stationary subtree is ONE
+    // table leaf (its value depends on |t1 - t2| only, so tables_kernel evaluates the subtree once
+    // per lattice distance — the same operations in the same order as element by element).
+    int32_t n_rops, n_tab;
+    uint8_t rops[NGP_MAX_OPS];          // NGP_OP_LINEAR, OP_TABLE, Plus / Times / ChangePoint (+ swapped)
+    uint8_t rslot[NGP_MAX_OPS];         // OP_TABLE: table slot; ChangePoint: sigmoid slot (= slot[] of the op)
+    uint8_t rpoff[NGP_MAX_OPS];         // Linear / ChangePoint: offset of the parameters
+    uint8_t tb_first[MAX_TABLES];       // table k tabulates ops[tb_first[k] .. tb_last[k]] (a postfix
+    uint8_t tb_last[MAX_TABLES];        //  range of the full program = one subtree)
 };
 static_assert(sizeof(DevProgram) % 8 == 0, "DevProgram is copied as 8-byte words");
 

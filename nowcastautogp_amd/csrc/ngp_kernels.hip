@@ -286,6 +286,8 @@ __global__ __launch_bounds__(256) void fill_kernel(JobGeom g, ChunkPtrs p, int n
 // O(n^2).  tables_kernel evaluates them once per item; fill_lattice_kernel is then pure
 // lookups + FMAs and runs at the HBM-write rate.
 // ---------------------------------------------------------------------------------------
+__device__ double keval_stat(const DevProgram &P, const DevSpec &sp, int first, int last, double d);
+
 __global__ __launch_bounds__(256) void tables_kernel(JobGeom g, ChunkPtrs p, DevSpec sp) {
     __shared__ DevProgram P;
     const int item = blockIdx.x;
@@ -296,6 +298,14 @@ __global__ __launch_bounds__(256) void tables_kernel(JobGeom g, ChunkPtrs p, Dev
     // gradient jobs: dt = [slot][3][R]: e (the leaf value without its amplitude) and the two
     // factors its lengthscale-type derivatives need, so the O(n^2) contraction is lookups + FMAs
     double *dt = p.dtab ? p.dtab + (long)item * g.maxstat * 3 * g.R : nullptr;
+    if (!dt) {
+        // value job: one table per maximal stationary subtree of the tree (reduced program)
+        for (int k = 0; k < P.n_tab; ++k) {
+            const int first = P.tb_first[k], last = P.tb_last[k];
+            for (int idx = threadIdx.x; idx < g.R; idx += 256)
+                tab[(long)k * g.R + idx] = keval_stat(P, sp, first, last, idx * g.h);
+        }
+    }
     int pi = 0;
     for (int i = 0; i < P.n_ops; ++i) {
         const int op = __builtin_amdgcn_readfirstlane((int)P.ops[i]);
@@ -304,37 +314,34 @@ __global__ __launch_bounds__(256) void tables_kernel(JobGeom g, ChunkPtrs p, Dev
         if (op == NGP_OP_SQEXP) {
             const double l = P.params[pi], a = P.params[pi + 1];
             const double den = sp.se_form ? l : l * l;
-            for (int k = threadIdx.x; k < g.R; k += 256) {
+            // leaf tables: gradient jobs only (value jobs tabulate whole subtrees, above)
+            for (int k = threadIdx.x; d0 && k < g.R; k += 256) {
                 const double d = k * g.h;
                 const double e = exp(-0.5 * d * d / den);
                 tab[(long)slot * g.R + k] = a * e;
-                if (d0) d0[k] = e;
+                d0[k] = e;
             }
             pi += 2;
         } else if (op == NGP_OP_GAMMAEXP) {
             const double l = P.params[pi], gam = P.params[pi + 1], a = P.params[pi + 2];
-            for (int k = threadIdx.x; k < g.R; k += 256) {
+            for (int k = threadIdx.x; d0 && k < g.R; k += 256) {
                 const double rr = k * g.h / l, u = pow(rr, gam), e = exp(-u);
                 tab[(long)slot * g.R + k] = a * e;
-                if (d0) {
-                    d0[k] = e;
-                    d0[g.R + k] = e * u;                                  // -> d / d lengthscale
-                    d0[2 * g.R + k] = (k > 0) ? e * u * log(rr) : 0.0;    // -> d / d gamma
-                }
+                d0[k] = e;
+                d0[g.R + k] = e * u;                                  // -> d / d lengthscale
+                d0[2 * g.R + k] = (k > 0) ? e * u * log(rr) : 0.0;    // -> d / d gamma
             }
             pi += 3;
         } else if (op == NGP_OP_PERIODIC) {
             const double l = P.params[pi], per = P.params[pi + 1], a = P.params[pi + 2];
             const double c = sp.periodic_form ? 2.0 / l : 2.0 / (l * l);
-            for (int k = threadIdx.x; k < g.R; k += 256) {
+            for (int k = threadIdx.x; d0 && k < g.R; k += 256) {
                 const double d = k * g.h, ang = M_PI * d / per;
                 const double sn = sin(ang), e = exp(-c * sn * sn);
                 tab[(long)slot * g.R + k] = a * e;
-                if (d0) {
-                    d0[k] = e;
-                    d0[g.R + k] = e * sn * sn;                 // -> d / d lengthscale
-                    d0[2 * g.R + k] = e * sn * cos(ang) * d;   // -> d / d period
-                }
+                d0[k] = e;
+                d0[g.R + k] = e * sn * sn;                 // -> d / d lengthscale
+                d0[2 * g.R + k] = e * sn * cos(ang) * d;   // -> d / d period
             }
             pi += 3;
         } else if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
@@ -396,8 +403,85 @@ __device__ __forceinline__ double keval_lattice(const DevProgram &P, const doubl
     return s0;
 }
 
+// Value of the stationary subtree ops[first..last] (a postfix range of the full program) at
+// distance d: the leaf formulas of tables_kernel / keval, operation for operation.
+__device__ double keval_stat(const DevProgram &P, const DevSpec &sp, int first, int last, double d) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+    for (int i = first; i <= last; ++i) {
+        const int op = __builtin_amdgcn_readfirstlane((int)P.ops[i]);
+        const int pi = __builtin_amdgcn_readfirstlane((int)P.poff[i]);
+        if (op < NGP_OP_PLUS) {
+            double v;
+            if (op == NGP_OP_CONSTANT) {
+                v = P.params[pi];
+            } else if (op == NGP_OP_SQEXP) {
+                const double l = P.params[pi];
+                const double den = sp.se_form ? l : l * l;
+                v = P.params[pi + 1] * exp(-0.5 * d * d / den);
+            } else if (op == NGP_OP_GAMMAEXP) {
+                const double rr = d / P.params[pi], u = pow(rr, P.params[pi + 1]);
+                v = P.params[pi + 2] * exp(-u);
+            } else {  // NGP_OP_PERIODIC
+                const double l = P.params[pi];
+                const double c = sp.periodic_form ? 2.0 / l : 2.0 / (l * l);
+                const double sn = sin(M_PI * d / P.params[pi + 1]);
+                v = P.params[pi + 2] * exp(-c * sn * sn);
+            }
+            s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+        } else {
+            const double v = (op == NGP_OP_PLUS) ? s1 + s0 : s1 * s0;
+            s0 = v; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+        }
+    }
+    return s0;
+}
+
+// k(t1, t2) on lattice times through the REDUCED program (DevProgram::rops): table leaves by
+// lattice distance dq, Linear in closed form, ChangePoint sigmoids by point
+__device__ __forceinline__ double keval_reduced(const DevProgram &P, const double *tab,
+                                                const double *sig, int R, int npts, double t1,
+                                                double t2, int dq, int pt1, int pt2) {
+    const int nops = P.n_rops;
+    if (nops == 1 && P.rops[0] == OP_TABLE) return tab[dq];   // the whole tree is stationary
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+    for (int i = 0; i < nops; ++i) {
+        const int op = __builtin_amdgcn_readfirstlane((int)P.rops[i]);
+        if (op == OP_TABLE || op == NGP_OP_LINEAR) {
+            double v;
+            if (op == OP_TABLE) {
+                const int slot = __builtin_amdgcn_readfirstlane((int)P.rslot[i]);
+                v = tab[(long)slot * R + dq];
+            } else {
+                const int pi = __builtin_amdgcn_readfirstlane((int)P.rpoff[i]);
+                const double c = P.params[pi];
+                v = P.params[pi + 1] + P.params[pi + 2] * (t1 - c) * (t2 - c);
+            }
+            s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
+        } else {
+            double v;
+            if (op == NGP_OP_PLUS) {
+                v = s1 + s0;
+            } else if (op == NGP_OP_TIMES) {
+                v = s1 * s0;
+            } else {
+                const int slot = __builtin_amdgcn_readfirstlane((int)P.rslot[i]);
+                const double kl = (op == NGP_OP_CHANGEPOINT) ? s1 : s0;
+                const double kr = (op == NGP_OP_CHANGEPOINT) ? s0 : s1;
+                const double g1 = sig[(long)slot * npts + pt1];
+                const double g2 = sig[(long)slot * npts + pt2];
+                v = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+            }
+            s0 = v; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+        }
+    }
+    return s0;
+}
+
 // split: workgroups per tile (1, 2, 4) — small launches are latency-bound on the 8 rows a thread
 // walks, so they are cut into more, shorter workgroups (as in the gradient contraction)
+// GRADJOB: the tables are per leaf (the contraction needs them that way) -> full program;
+// otherwise per maximal stationary subtree -> reduced program
+template <bool GRADJOB>
 __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs p, int ntri,
                                                            int tile_off, int split, DevSpec sp) {
     __shared__ DevProgram P;
@@ -430,6 +514,11 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
     const double *sig = p.sig + (long)item * g.maxcp * g.npts;
     const int naux_t = g.da + g.m;
     const double *y0 = p.y0 + (g.y_shared ? 0 : (long)item * g.n0);
+    auto kev = [&](const DevProgram &Pp, const double *tb, const double *sg, int R, int npts,
+                   double t1, double t2, int dq, int pt1, int pt2) -> double {
+        if constexpr (GRADJOB) return keval_lattice(Pp, tb, sg, R, npts, t1, t2, dq, pt1, pt2);
+        else return keval_reduced(Pp, tb, sg, R, npts, t1, t2, dq, pt1, pt2);
+    };
     for (int rr = 0; rr < nrows; ++rr) {
         const int lr = ty * 8 + sub * nrows + rr;
         f64x2 v;
@@ -438,8 +527,8 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
             row = (long)r * NB + lr;
             const int q1 = p.qpts[row];
             const double t1 = p.t0[row];
-            v.x = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2a, abs(q1 - q2a), (int)row, col);
-            v.y = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2b, abs(q1 - q2b), (int)row, col + 1);
+            v.x = kev(P, tab, sig, g.R, g.npts, t1, t2a, abs(q1 - q2a), (int)row, col);
+            v.y = kev(P, tab, sig, g.R, g.npts, t1, t2b, abs(q1 - q2b), (int)row, col + 1);
             if (row == col) v.x += diag;
             if (row == col + 1) v.y += diag;
             if (row >= g.n_real || col >= g.n_real) v.x = (row == col) ? 1.0 : 0.0;
@@ -455,8 +544,8 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
             if (ar < naux_t) {
                 const int q1 = p.qpts[g.n0 + ar];
                 const double t1 = p.taux[ar];
-                v.x = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2a, abs(q1 - q2a), g.n0 + ar, col);
-                v.y = keval_lattice(P, tab, sig, g.R, g.npts, t1, t2b, abs(q1 - q2b), g.n0 + ar, col + 1);
+                v.x = kev(P, tab, sig, g.R, g.npts, t1, t2a, abs(q1 - q2a), g.n0 + ar, col);
+                v.y = kev(P, tab, sig, g.R, g.npts, t1, t2b, abs(q1 - q2b), g.n0 + ar, col + 1);
             } else if (ar == naux_t) {
                 v.x = y0[col];
                 v.y = y0[col + 1];
@@ -1537,98 +1626,150 @@ __device__ __forceinline__ void load_frag8_t(Frag8<4> &f, const double *p, long 
     }
 }
 
+// NIT: 16-row groups of the aux tile that hold real rows (1 for the usual d + m + 1 <= 16, else 4).
+// The four waves of a workgroup take four different b and share A_c through LDS.
+template <int NIT>
 __global__ __launch_bounds__(256, 2) void aux_back_update_kernel(JobGeom g, ChunkPtrs p, int c) {
+    constexpr int PITCH = NB + 2;
+    __shared__ __attribute__((aligned(16))) double Acs[16 * NIT][PITCH];
     const int item = map_item(p, blockIdx.y);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ntl = (g.naux + NB - 1) / NB;          // aux tiles that hold real rows
-    const int idx = blockIdx.x * 4 + wave;
-    if (idx >= ntl * c) return;
-    const int at = idx % ntl, b = idx / ntl;
+    const int ngrp = (c + 3) / 4;                    // workgroups per aux tile
+    const int at = blockIdx.x / ngrp, b = (blockIdx.x % ngrp) * 4 + wave;
     const long ld = g.ld;
     double *Lit = p.L + (long)item * g.item_stride;
-    double *Wa = Lit + ((long)g.n0 + (long)at * NB) * ld;          // aux tile rows (B operand)
-    const double *Lcb = Lit + (long)c * NB * ld + (long)b * NB;    // L tile (c, b), A operand^T
+    double *Wa = Lit + ((long)g.n0 + (long)at * NB) * ld;          // aux tile rows
+    for (int e = threadIdx.x; e < 16 * NIT * NB; e += 256) {
+        const int r = e >> 6, k = e & 63;
+        Acs[r][k] = Wa[(long)r * ld + c * NB + k];                 // A_c (aux_back_solve_kernel)
+    }
+    __syncthreads();
+    if (b >= c) return;
+    const double *Lcb = Lit + (long)c * NB * ld + (long)b * NB;    // L tile (c, b), read transposed
     const int r16 = lane & 15, q = lane >> 4;
-    double acc4[4][4][4];
+    double acc4[4][NIT][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
+        for (int y = 0; y < NIT; ++y)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[x][y][r] = 0.0;
     // S'[jj][a] = sum_k L[64 c + k][64 b + jj] A_c[a][k]
     const double *pa = Lcb + (long)(2 * q) * ld + r16;
-    const double *pb = Wa + (long)r16 * ld + c * NB + 2 * q;
-    Frag8<4> a[3], bb[3];             // 8-deep stages, two of them in flight ahead of the MFMAs
-    load_frag8_t(a[0], pa, ld);
-    load_frag8(bb[0], pb, ld);
-    load_frag8_t(a[1], pa + 8 * ld, ld);
-    load_frag8(bb[1], pb + 8, ld);
+    Frag8<4> a[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) load_frag8_t(a[s], pa + (long)(8 * s) * ld, ld);   // whole tile in flight
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        if (s + 2 < 8) {
-            load_frag8_t(a[(s + 2) % 3], pa + (long)(8 * (s + 2)) * ld, ld);
-            load_frag8(bb[(s + 2) % 3], pb + 8 * (s + 2), ld);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const f64x2 bv = *reinterpret_cast<const f64x2 *>(&Acs[16 * it + r16][8 * s + 2 * q]);
+            const Rot4 bx = rot4(bv.x);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[s].v[jt].x, bx);
+            const Rot4 by = rot4(bv.y);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[s].v[jt].y, by);
         }
-        mfma_frag8(acc4, a[s % 3], bb[s % 3]);
     }
-    subtract_in_place_perm(Wa, ld, b * NB, acc4, lane);
+    // Wa[a][64 b + jj] -= S'[jj][a]
+    const int jj0 = 4 * (r16 >> 2) + q;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double *e = Wa + (long)(16 * it + ((r16 + 4 * r) & 15)) * ld + b * NB + 16 * jt + jj0;
+                *e -= acc4[jt][it][r];
+            }
 }
 
-// R[:, col] = X[:, col] - sum_row A[:, row] K[row][col]: one thread per column, the rows of A it
-// multiplies are wave-uniform (LDS broadcast), K comes from the lattice tables (or the direct
-// interpreter) element by element and is never stored.  One workgroup per (256 columns, item, aux
-// tile); rows are walked in slabs of KA_ROWS so that a slab of A sits in LDS.
-constexpr int KA_ROWS = NB;   // n0 is a multiple of NB: every slab is whole
-template <int NACC>
+// R[:, col] = X[:, col] - sum_row A[:, row] K[row][col]: one thread per column (or two), the rows of
+// A it multiplies are wave-uniform (LDS broadcast), K comes from the lattice tables (or the direct
+// interpreter) element by element and is never stored.  One workgroup per (256 CPT columns, item,
+// NACC aux rows); rows are walked in slabs of 64 whose A block, times and lattice coordinates sit
+// in LDS.
+// Two kernels, each item is taken by exactly one of them (the other returns at once):
+//   SINGLE   the item's tree is stationary as a whole = ONE table (DevProgram::rops): no interpreter
+//            in the loop, two columns per thread, gathers issued eight rows ahead
+//   general  reduced-program interpreter (or the direct one off-lattice), one column per thread
+template <int NACC, int CPT, bool SINGLE>
 __global__ __launch_bounds__(256) void kapply_kernel(JobGeom g, ChunkPtrs p, const double *A,
                                                      const double *X, double *Rout, DevSpec sp) {
     __shared__ DevProgram P;
-    __shared__ double As[NACC][KA_ROWS];
+    __shared__ double As[NACC][NB];
+    __shared__ double t1s[NB];
+    __shared__ int q1s[NB];
     const int item = map_item(p, blockIdx.y), tid = threadIdx.x;
     const int a0 = blockIdx.z * NACC;
     const int rows = min(NACC, g.naux - a0);
     if (rows <= 0) return;
     load_program(&P, p.progs + item);
     __syncthreads();
+    const bool single = g.lattice && P.n_rops == 1 && P.rops[0] == OP_TABLE;   // workgroup-uniform
+    if (single != SINGLE) return;
     const long ld = g.ld;
     const double *Ai = A + ((long)item * g.naux_pad + a0) * ld;
     const double *Xi = X + ((long)item * g.naux_pad + a0) * ld;
     double *Ri = Rout + ((long)item * g.naux_pad + a0) * ld;
     const double *tab = g.lattice ? p.tab + (long)item * g.maxstat * g.R : nullptr;
     const double *sig = g.lattice ? p.sig + (long)item * g.maxcp * g.npts : nullptr;
-    const int col = blockIdx.x * 256 + tid;          // n0 is a multiple of 64, the grid of 256
-    const bool live = col < g.n0;
-    const int colc = live ? col : g.n0 - 1;
-    const double t2 = p.t0[colc];
-    const int q2 = g.lattice ? p.qpts[colc] : 0;
-    const double diag = P.noise + sp.jitter;
-    double acc[NACC];
+    int col[CPT], q2[CPT];
+    double t2[CPT];
+    bool live[CPT];
 #pragma unroll
-    for (int s = 0; s < NACC; ++s) acc[s] = 0.0;
-    for (int r0 = 0; r0 < g.n0; r0 += KA_ROWS) {
+    for (int u = 0; u < CPT; ++u) {
+        const int cidx = (blockIdx.x * CPT + u) * 256 + tid;
+        live[u] = cidx < g.n0;
+        col[u] = live[u] ? cidx : g.n0 - 1;
+        t2[u] = p.t0[col[u]];
+        q2[u] = g.lattice ? p.qpts[col[u]] : 0;
+    }
+    if (blockIdx.x * CPT * 256 >= g.n0) return;   // whole workgroup: the grid is sized for CPT = 1
+    const double diag = P.noise + sp.jitter;
+    double acc[CPT][NACC];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u)
+#pragma unroll
+        for (int s = 0; s < NACC; ++s) acc[u][s] = 0.0;
+    for (int r0 = 0; r0 < g.n0; r0 += NB) {
         __syncthreads();
-        for (int e = tid; e < NACC * KA_ROWS; e += 256) {
-            const int a = e / KA_ROWS, rr = e % KA_ROWS;
+        for (int e = tid; e < NACC * NB; e += 256) {
+            const int a = e >> 6, rr = e & 63;
             As[a][rr] = (a < rows) ? Ai[(long)a * ld + r0 + rr] : 0.0;
         }
+        if (tid < NB) {
+            t1s[tid] = p.t0[r0 + tid];
+            q1s[tid] = g.lattice ? p.qpts[r0 + tid] : 0;
+        }
         __syncthreads();
-#pragma unroll 2
-        for (int rr = 0; rr < KA_ROWS; ++rr) {
+#pragma unroll SINGLE ? 8 : 1
+        for (int rr = 0; rr < NB; ++rr) {
             const int row = r0 + rr;
-            const double t1 = p.t0[row];
-            double v = g.lattice ? keval_lattice(P, tab, sig, g.R, g.npts, t1, t2,
-                                                 abs(p.qpts[row] - q2), row, colc)
-                                 : keval(P, sp, t1, t2);
-            if (row == colc) v += diag;
-            if (row >= g.n_real || colc >= g.n_real) v = (row == colc) ? 1.0 : 0.0;
 #pragma unroll
-            for (int s = 0; s < NACC; ++s) acc[s] += As[s][rr] * v;
+            for (int u = 0; u < CPT; ++u) {
+                double v;
+                if constexpr (SINGLE)
+                    v = tab[abs(q1s[rr] - q2[u])];
+                else
+                    v = g.lattice ? keval_reduced(P, tab, sig, g.R, g.npts, t1s[rr], t2[u],
+                                                  abs(q1s[rr] - q2[u]), row, col[u])
+                                  : keval(P, sp, t1s[rr], t2[u]);
+                if (row == col[u]) v += diag;
+#pragma unroll
+                for (int s = 0; s < NACC; ++s) acc[u][s] += As[s][rr] * v;
+            }
         }
     }
-    if (live)
-        for (int s = 0; s < rows; ++s) Ri[(long)s * ld + col] = Xi[(long)s * ld + col] - acc[s];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u)
+        if (live[u]) {
+#pragma unroll
+            for (int s = 0; s < NACC; ++s)   // static index: a runtime bound sends acc[] to scratch
+                if (s < rows) Ri[(long)s * ld + col[u]] = Xi[(long)s * ld + col[u]] - acc[u][s];
+        }
 }
 
 // S[a][b] = A_a . X_b + R_a . A_b and T[a][b] = R_a . A_b for all naux^2 pairs, one wave per pair
@@ -1777,7 +1918,7 @@ __global__ __launch_bounds__(64) void epilogue_kernel(JobGeom g, EpiPtrs p, DevS
     const double *sig = p.sig ? p.sig + (long)item * g.maxcp * g.npts : nullptr;
     auto kaux = [&](int u, int v) -> double {   // u, v index taux: appended points then forecast points
         if (tab)
-            return keval_lattice(P, tab, sig, g.R, g.npts, p.taux[u], p.taux[v],
+            return keval_reduced(P, tab, sig, g.R, g.npts, p.taux[u], p.taux[v],
                                  abs(p.qpts[g.n0 + u] - p.qpts[g.n0 + v]), g.n0 + u, g.n0 + v);
         return keval(P, sp, p.taux[u], p.taux[v]);
     };
@@ -2503,8 +2644,12 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
     if (g.lattice) {
         const long nwg = (long)(ntiles - off) * Bc;
         const int split = nwg <= 1024 ? 4 : (nwg <= 2048 ? 2 : 1);
-        hipLaunchKernelGGL(fill_lattice_kernel, dim3((ntiles - off) * split, Bc), dim3(256), 0, s, g,
-                           p, ntri, off, split, sp);
+        if (p.dtab)
+            hipLaunchKernelGGL(fill_lattice_kernel<true>, dim3((ntiles - off) * split, Bc), dim3(256),
+                               0, s, g, p, ntri, off, split, sp);
+        else
+            hipLaunchKernelGGL(fill_lattice_kernel<false>, dim3((ntiles - off) * split, Bc),
+                               dim3(256), 0, s, g, p, ntri, off, split, sp);
     }
     else
         hipLaunchKernelGGL(fill_kernel, dim3(ntiles - off, Bc), dim3(256), 0, s, g, p, ntri, off, sp);
@@ -2552,17 +2697,25 @@ void launch_aux_back(const JobGeom &g, const ChunkPtrs &p, const double *dinv_al
     const int ntl = (g.naux + NB - 1) / NB;
     hipLaunchKernelGGL(aux_back_solve_kernel, dim3(ntl, Bc), dim3(256), 0, s, g, p,
                        dinv_all + (size_t)c * mstep, Aout, accumulate, c);
-    if (c > 0)
-        hipLaunchKernelGGL(aux_back_update_kernel, dim3((ntl * c + 3) / 4, Bc), dim3(256), 0, s, g,
-                           p, c);
+    if (c > 0) {
+        const int ngrp = (c + 3) / 4;
+        if (g.naux <= 16)
+            hipLaunchKernelGGL(aux_back_update_kernel<1>, dim3(ntl * ngrp, Bc), dim3(256), 0, s, g,
+                               p, c);
+        else
+            hipLaunchKernelGGL(aux_back_update_kernel<4>, dim3(ntl * ngrp, Bc), dim3(256), 0, s, g,
+                               p, c);
+    }
 }
 
 void launch_kapply(const JobGeom &g, const ChunkPtrs &p, const double *A, const double *X,
                    double *R, int Bc, const DevSpec &sp, hipStream_t s) {
-    // accumulators per thread: 16 aux rows at a time (the usual d + m + 1 <= 16 is one pass)
-    constexpr int NACC = 16;
-    hipLaunchKernelGGL(kapply_kernel<NACC>, dim3((g.n0 + 255) / 256, Bc, (g.naux + NACC - 1) / NACC),
-                       dim3(256), 0, s, g, p, A, X, R, sp);
+    // accumulators per thread and column: 12 aux rows at a time (the usual d + m + 1 = 11 is one pass)
+    constexpr int NACC = 12;
+    const dim3 grid((g.n0 + 255) / 256, Bc, (g.naux + NACC - 1) / NACC);
+    if (g.lattice)
+        hipLaunchKernelGGL((kapply_kernel<NACC, 2, true>), grid, dim3(256), 0, s, g, p, A, X, R, sp);
+    hipLaunchKernelGGL((kapply_kernel<NACC, 1, false>), grid, dim3(256), 0, s, g, p, A, X, R, sp);
 }
 
 void launch_refine_gram(const JobGeom &g, const double *A, const double *X, const double *R,
