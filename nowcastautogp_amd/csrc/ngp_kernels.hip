@@ -1688,63 +1688,80 @@ __global__ __launch_bounds__(256, 2) void aux_back_update_kernel(JobGeom g, Chun
 
 // R[:, col] = X[:, col] - sum_row A[:, row] K[row][col]: one thread per column (or two), the rows of
 // A it multiplies are wave-uniform (LDS broadcast), K comes from the lattice tables (or the direct
-// interpreter) element by element and is never stored.  One workgroup per (256 CPT columns, item,
+// interpreter) element by element and is never stored.  One workgroup per (64 CPT columns, item,
 // NACC aux rows); rows are walked in slabs of 64 whose A block, times and lattice coordinates sit
 // in LDS.
-// Two kernels, each item is taken by exactly one of them (the other returns at once):
-//   SINGLE   the item's tree is stationary as a whole = ONE table (DevProgram::rops): no interpreter
-//            in the loop, two columns per thread, gathers issued eight rows ahead
-//   general  reduced-program interpreter (or the direct one off-lattice), one column per thread
-template <int NACC, int CPT, bool SINGLE>
+// Three instantiations; on a lattice each item is taken by exactly one of the first two (the other
+// returns at once):
+//   KA_SINGLE   the item's tree is stationary as a whole = ONE table (DevProgram::rops): no
+//               interpreter in the loop, two columns per thread, gathers issued eight rows ahead
+//   KA_REDUCED  reduced-program interpreter, one column per thread (kept apart from KA_DIRECT: the
+//               transcendental code of the direct interpreter cost it half its occupancy)
+//   KA_DIRECT   irregular times: direct evaluation of the full program
+enum { KA_SINGLE = 0, KA_REDUCED = 1, KA_DIRECT = 2 };
+// Workgroup = 64 CPT columns x 4 row quarters: wave w walks the w-th quarter of the rows for the
+// same columns and the four partial sums are added in wave order through LDS.  (One wave walking
+// all n0 rows was the critical path: a launch took as long as the item with the longest program.)
+template <int NACC, int CPT, int MODE>
 __global__ __launch_bounds__(256) void kapply_kernel(JobGeom g, ChunkPtrs p, const double *A,
                                                      const double *X, double *Rout, DevSpec sp) {
     __shared__ DevProgram P;
-    __shared__ double As[NACC][NB];
-    __shared__ double t1s[NB];
-    __shared__ int q1s[NB];
-    const int item = map_item(p, blockIdx.y), tid = threadIdx.x;
+    __shared__ double As[4][NACC][NB];
+    __shared__ double t1s[4][NB];
+    __shared__ int q1s[4][NB];
+    __shared__ double red[3][CPT][NACC][64];
+    const int item = map_item(p, blockIdx.y), tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int a0 = blockIdx.z * NACC;
     const int rows = min(NACC, g.naux - a0);
     if (rows <= 0) return;
+    if (blockIdx.x * CPT * 64 >= g.n0) return;    // whole workgroup: the grid is sized for CPT = 1
     load_program(&P, p.progs + item);
     __syncthreads();
-    const bool single = g.lattice && P.n_rops == 1 && P.rops[0] == OP_TABLE;   // workgroup-uniform
-    if (single != SINGLE) return;
+    constexpr bool SINGLE = MODE == KA_SINGLE;
+    if constexpr (MODE != KA_DIRECT) {
+        const bool single = P.n_rops == 1 && P.rops[0] == OP_TABLE;   // workgroup-uniform
+        if (single != SINGLE) return;
+    }
     const long ld = g.ld;
     const double *Ai = A + ((long)item * g.naux_pad + a0) * ld;
     const double *Xi = X + ((long)item * g.naux_pad + a0) * ld;
     double *Ri = Rout + ((long)item * g.naux_pad + a0) * ld;
-    const double *tab = g.lattice ? p.tab + (long)item * g.maxstat * g.R : nullptr;
-    const double *sig = g.lattice ? p.sig + (long)item * g.maxcp * g.npts : nullptr;
+    const double *tab = MODE != KA_DIRECT ? p.tab + (long)item * g.maxstat * g.R : nullptr;
+    const double *sig = MODE != KA_DIRECT ? p.sig + (long)item * g.maxcp * g.npts : nullptr;
     int col[CPT], q2[CPT];
     double t2[CPT];
     bool live[CPT];
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
-        const int cidx = (blockIdx.x * CPT + u) * 256 + tid;
+        const int cidx = (blockIdx.x * CPT + u) * 64 + lane;
         live[u] = cidx < g.n0;
         col[u] = live[u] ? cidx : g.n0 - 1;
         t2[u] = p.t0[col[u]];
-        q2[u] = g.lattice ? p.qpts[col[u]] : 0;
+        q2[u] = MODE != KA_DIRECT ? p.qpts[col[u]] : 0;
     }
-    if (blockIdx.x * CPT * 256 >= g.n0) return;   // whole workgroup: the grid is sized for CPT = 1
     const double diag = P.noise + sp.jitter;
     double acc[CPT][NACC];
 #pragma unroll
     for (int u = 0; u < CPT; ++u)
 #pragma unroll
         for (int s = 0; s < NACC; ++s) acc[u][s] = 0.0;
-    for (int r0 = 0; r0 < g.n0; r0 += NB) {
+    const int per = (g.nb0 + 3) / 4;              // 64-row slabs per wave
+    for (int sl = 0; sl < per; ++sl) {
+        const int slab = w * per + sl;
+        const bool on = slab < g.nb0;             // wave-uniform
+        const int r0 = slab * NB;
         __syncthreads();
-        for (int e = tid; e < NACC * NB; e += 256) {
-            const int a = e >> 6, rr = e & 63;
-            As[a][rr] = (a < rows) ? Ai[(long)a * ld + r0 + rr] : 0.0;
-        }
-        if (tid < NB) {
-            t1s[tid] = p.t0[r0 + tid];
-            q1s[tid] = g.lattice ? p.qpts[r0 + tid] : 0;
+        if (on) {
+            for (int e = lane; e < NACC * NB; e += 64) {
+                const int a = e >> 6, rr = e & 63;
+                As[w][a][rr] = (a < rows) ? Ai[(long)a * ld + r0 + rr] : 0.0;
+            }
+            t1s[w][lane] = p.t0[r0 + lane];
+            q1s[w][lane] = MODE != KA_DIRECT ? p.qpts[r0 + lane] : 0;
         }
         __syncthreads();
+        if (!on) continue;
 #pragma unroll SINGLE ? 8 : 1
         for (int rr = 0; rr < NB; ++rr) {
             const int row = r0 + rr;
@@ -1752,23 +1769,37 @@ __global__ __launch_bounds__(256) void kapply_kernel(JobGeom g, ChunkPtrs p, con
             for (int u = 0; u < CPT; ++u) {
                 double v;
                 if constexpr (SINGLE)
-                    v = tab[abs(q1s[rr] - q2[u])];
+                    v = tab[abs(q1s[w][rr] - q2[u])];
+                else if constexpr (MODE == KA_REDUCED)
+                    v = keval_reduced(P, tab, sig, g.R, g.npts, t1s[w][rr], t2[u],
+                                      abs(q1s[w][rr] - q2[u]), row, col[u]);
                 else
-                    v = g.lattice ? keval_reduced(P, tab, sig, g.R, g.npts, t1s[rr], t2[u],
-                                                  abs(q1s[rr] - q2[u]), row, col[u])
-                                  : keval(P, sp, t1s[rr], t2[u]);
+                    v = keval(P, sp, t1s[w][rr], t2[u]);
                 if (row == col[u]) v += diag;
 #pragma unroll
-                for (int s = 0; s < NACC; ++s) acc[u][s] += As[s][rr] * v;
+                for (int s = 0; s < NACC; ++s) acc[u][s] += As[w][s][rr] * v;
             }
         }
     }
+    __syncthreads();
+    if (w > 0) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u)
+#pragma unroll
+            for (int s = 0; s < NACC; ++s) red[w - 1][u][s][lane] = acc[u][s];
+    }
+    __syncthreads();
+    if (w > 0) return;
 #pragma unroll
     for (int u = 0; u < CPT; ++u)
         if (live[u]) {
 #pragma unroll
             for (int s = 0; s < NACC; ++s)   // static index: a runtime bound sends acc[] to scratch
-                if (s < rows) Ri[(long)s * ld + col[u]] = Xi[(long)s * ld + col[u]] - acc[u][s];
+                if (s < rows) {
+                    const double sum = ((acc[u][s] + red[0][u][s][lane]) + red[1][u][s][lane]) +
+                                       red[2][u][s][lane];
+                    Ri[(long)s * ld + col[u]] = Xi[(long)s * ld + col[u]] - sum;
+                }
         }
 }
 
@@ -2712,10 +2743,16 @@ void launch_kapply(const JobGeom &g, const ChunkPtrs &p, const double *A, const 
                    double *R, int Bc, const DevSpec &sp, hipStream_t s) {
     // accumulators per thread and column: 12 aux rows at a time (the usual d + m + 1 = 11 is one pass)
     constexpr int NACC = 12;
-    const dim3 grid((g.n0 + 255) / 256, Bc, (g.naux + NACC - 1) / NACC);
-    if (g.lattice)
-        hipLaunchKernelGGL((kapply_kernel<NACC, 2, true>), grid, dim3(256), 0, s, g, p, A, X, R, sp);
-    hipLaunchKernelGGL((kapply_kernel<NACC, 1, false>), grid, dim3(256), 0, s, g, p, A, X, R, sp);
+    const dim3 grid(g.nb0, Bc, (g.naux + NACC - 1) / NACC);   // 64 columns per workgroup (CPT = 1)
+    if (g.lattice) {
+        hipLaunchKernelGGL((kapply_kernel<NACC, 2, KA_SINGLE>), grid, dim3(256), 0, s, g, p, A, X, R,
+                           sp);
+        hipLaunchKernelGGL((kapply_kernel<NACC, 1, KA_REDUCED>), grid, dim3(256), 0, s, g, p, A, X,
+                           R, sp);
+    } else {
+        hipLaunchKernelGGL((kapply_kernel<NACC, 1, KA_DIRECT>), grid, dim3(256), 0, s, g, p, A, X,
+                           R, sp);
+    }
 }
 
 void launch_refine_gram(const JobGeom &g, const double *A, const double *X, const double *R,
