@@ -34,33 +34,80 @@ def shard(P_total: int, rank: Optional[int] = None, size: Optional[int] = None) 
     return slice(lo, lo + base + (1 if rank < rem else 0))
 
 
-def all_gather_rows(x: np.ndarray, device=None) -> np.ndarray:
-    """Concatenate per-rank arrays along axis 0 in rank order (equal shapes on every rank)."""
+def deal_round_robin(costs: Sequence[float], size: Optional[int] = None) -> List[np.ndarray]:
+    """Load-balanced assignment of items to ranks: sort by cost (kernel
+    tree size: the fill and the table passes scale with it), deal round-robin.  Returns, per rank,
+    the indices it owns; identical on every rank (stable sort, no communication)."""
+    size = world()[1] if size is None else size
+    order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable")
+    return [np.sort(order[r::size]) for r in range(size)]
+
+
+def shard_sizes(n_local: int, device=None) -> np.ndarray:
+    """Rows every rank contributes to an all_gather_rows (shards may be ragged: P % world != 0)."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return np.array([n_local], dtype=np.int64)
+    import torch
+    t = torch.tensor([n_local], dtype=torch.int64)
+    if d.get_backend() == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    out = torch.empty(d.get_world_size(), dtype=torch.int64, device=t.device)
+    d.all_gather_into_tensor(out, t)
+    return out.cpu().numpy()
+
+
+def all_gather_rows(x: np.ndarray, device=None, sizes: Optional[np.ndarray] = None) -> np.ndarray:
+    """Concatenate per-rank arrays along axis 0 in rank order.  Row counts may differ between
+    ranks (block partition with a remainder): shards are padded to the longest for the one
+    collective and trimmed afterwards.  ``sizes``: the per-rank row counts if the caller already
+    has them (saves the small all-gather that finds them)."""
     d = _dist()
     x = np.ascontiguousarray(x, dtype=np.float64)
     if d is None or d.get_world_size() == 1:
         return x
     import torch
-    t = torch.from_numpy(x)
+    if sizes is None:
+        sizes = shard_sizes(x.shape[0], device)
+    nmax = int(sizes.max())
+    pad = np.zeros((nmax,) + x.shape[1:])
+    pad[:x.shape[0]] = x
+    t = torch.from_numpy(pad)
     if d.get_backend() == "nccl":
         t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
-    out = torch.empty((d.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype,
+    out = torch.empty((d.get_world_size() * nmax,) + tuple(t.shape[1:]), dtype=t.dtype,
                       device=t.device)
     d.all_gather_into_tensor(out, t)
-    return out.cpu().numpy()
+    full = out.cpu().numpy()
+    if (sizes == nmax).all():
+        return full
+    return np.concatenate([full[r * nmax:r * nmax + int(sizes[r])] for r in range(len(sizes))])
 
 
-def normalize_log_weights(logw_local: np.ndarray, device=None):
+def block_sizes(P_total: int, size: Optional[int] = None) -> np.ndarray:
+    """Rows per rank of the block partition ``shard`` makes (no communication)."""
+    size = world()[1] if size is None else size
+    return np.array([shard(P_total, r, size).stop - shard(P_total, r, size).start
+                     for r in range(size)], dtype=np.int64)
+
+
+def normalize_log_weights(logw_local: np.ndarray, device=None, P_total: Optional[int] = None):
     """logw_local: [P_local] or [P_local, D] (one column per scenario).  Returns this rank's
     slice of the normalised weights and the effective sample size per column, both computed
-    over ALL ranks' particles through the C-ABI's ngp_weights_normalize."""
+    over ALL ranks' particles through the C-ABI's ngp_weights_normalize.  ONE collective when the
+    caller states ``P_total`` (the block partition then gives every rank's row count); otherwise a
+    second small one finds the counts."""
     lw = np.asarray(logw_local, dtype=np.float64)
     one = lw.ndim == 1
     if one:
         lw = lw[:, None]
-    allw = all_gather_rows(lw, device)
+    sizes = block_sizes(P_total) if P_total is not None else shard_sizes(lw.shape[0], device)
+    if int(sizes[world()[0]]) != lw.shape[0]:
+        raise ValueError("normalize_log_weights: this rank's rows do not match the block partition "
+                         f"of P_total={P_total}")
+    allw = all_gather_rows(lw, device, sizes)
     r, _ = world()
-    lo = r * lw.shape[0]
+    lo = int(sizes[:r].sum())
     w = np.empty_like(lw)
     ess = np.empty(lw.shape[1])
     for s in range(lw.shape[1]):

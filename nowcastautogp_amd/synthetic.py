@@ -109,3 +109,19 @@ def jitter_programs(programs, copies: int, rng: np.random.Generator, rel: float 
                     p[j] *= f[j]
             out.append((ops, p, float(noise * math.exp(rel * rng.standard_normal()))))
     return out
+
+
+def bench_items(name: str = "C3", rank: int = 0, n: int | None = None, P: int | None = None,
+                D: int | None = None):
+    """The (particle, scenario) items of one ``bench.py`` step on one rank: every item its own
+    kernel (``jitter_programs``) over the n + d points of its scenario.  Shared by the GPU leg and
+    by ``oracle/cpu_baseline.py`` so both see identical items.  Returns (workload, programs,
+    Y [B, n + d], t [n + d])."""
+    w = make_workload(name, n=n, P=P, D=D, seed_offset=rank)
+    Pn, Dn, nn, d = len(w.programs), w.y_add.shape[0], w.n, w.t_add.size
+    rng = np.random.Generator(np.random.PCG64(99 + rank))
+    progs = jitter_programs(w.programs, Dn, rng) if Dn > 1 else list(w.programs)
+    Y = np.empty((Pn * Dn, nn + d))
+    Y[:, :nn] = w.y
+    Y[:, nn:] = np.tile(w.y_add, (Pn, 1))
+    return w, progs, Y, np.concatenate([w.t, w.t_add])
