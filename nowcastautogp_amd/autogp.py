@@ -180,12 +180,40 @@ class Particle:
         return ops, params, self.noise
 
 
+def make_streams(seed: Optional[int] = None):
+    """(shared, local) random streams of a model.
+
+    ``shared`` is the SAME stream on every rank (data-annealing permutation, flat-series jitter,
+    resampling ancestors, mixture draws): it is seeded from ``seed``, or — ``seed is None`` — from
+    rank 0's entropy, broadcast.  ``local`` differs per rank (particle initialisation, structure
+    and HMC moves): a rank that shared it would hold a copy of rank 0's particles.  With one rank
+    both still exist, so a run does not change its draws when it is sharded."""
+    rank, world = distributed.world()
+    if seed is None:
+        root = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).astype(np.uint64)
+                   @ np.array([1, 2**31], dtype=np.uint64)) % (2**62)
+        if world > 1:
+            root = distributed.broadcast_int(root)
+    else:
+        root = int(seed)
+    shared = np.random.Generator(np.random.PCG64(np.random.SeedSequence([root, 0])))
+    local = np.random.Generator(np.random.PCG64(np.random.SeedSequence([root, 1, rank])))
+    return shared, local
+
+
+def child_stream(rng: np.random.Generator) -> np.random.Generator:
+    """An independent stream split off ``rng`` (which advances): the per-scenario clones of
+    forecast_with_nowcasts each get their own, as the reference's tasks do."""
+    return np.random.Generator(np.random.PCG64(int(rng.integers(0, 2**63 - 1))))
+
+
 class GPModel:
     """Ensemble of SMC particles over kernel structures.  Observable fields used by the
     reference's tests: ``config`` (identity preserved, test/test_gpconfig.jl:9), ``ds``, ``y``."""
 
     def __init__(self, ds=None, y=None, *, n_particles: int = 8, config: Optional[gp.GPConfig] = None,
-                 engine=None, seed: Optional[int] = None, depth_cap: int = 6, _from=None):
+                 engine=None, seed: Optional[int] = None, depth_cap: int = 6, _from=None,
+                 _streams=None):
         if isinstance(ds, dict) and y is None:
             _from = ds
         self.engine = engine
@@ -205,7 +233,7 @@ class GPModel:
         self.ds_transform = _ds_transform(self.days)
         self.y_transform = _y_transform(self.y)
         self.depth_cap = depth_cap
-        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.rng_shared, self.rng = _streams if _streams is not None else make_streams(seed)
         self.n_particles_total = int(n_particles)
         sl = distributed.shard(self.n_particles_total)
         nloc = sl.stop - sl.start
@@ -277,6 +305,7 @@ class GPModel:
             "log_weights": self.log_weights.copy(), "n_obs": self.n_obs,
             "perm": self._perm.copy(), "logml": self._logml.copy(),
             "rng_state": copy.deepcopy(self.rng.bit_generator.state),
+            "rng_shared_state": copy.deepcopy(self.rng_shared.bit_generator.state),
         }
 
     def _load(self, d: dict):
@@ -294,6 +323,9 @@ class GPModel:
         self._logml = np.array(d["logml"], float)
         self.rng = np.random.Generator(np.random.PCG64())
         self.rng.bit_generator.state = copy.deepcopy(d["rng_state"])
+        self.rng_shared = np.random.Generator(np.random.PCG64())
+        self.rng_shared.bit_generator.state = copy.deepcopy(d.get("rng_shared_state",
+                                                                  d["rng_state"]))
 
     @classmethod
     def from_dict(cls, d: dict, engine=None) -> "GPModel":
@@ -308,7 +340,8 @@ def num_particles(model: GPModel) -> int:
 # weights / resampling — the only cross-particle (and, multi-GPU, cross-rank) step
 # ---------------------------------------------------------------------------------------------
 def _normalized_weights(model: GPModel):
-    w, ess = distributed.normalize_log_weights(model.log_weights)
+    w, ess = distributed.normalize_log_weights(model.log_weights,
+                                               P_total=model.n_particles_total)
     return w, ess
 
 
@@ -324,10 +357,9 @@ def maybe_resample(model: GPModel, ess_threshold: float) -> bool:
     w_loc, ess = _normalized_weights(model)
     if not (ess < ess_threshold):
         return False
-    w_all = distributed.all_gather_rows(w_loc[:, None])[:, 0]
-    seed = int(model.rng.integers(0, 2**31 - 1))
-    if distributed.world()[1] > 1:   # every rank must draw the same ancestors
-        seed = int(distributed.all_gather_rows(np.array([[float(seed)]]))[0, 0])
+    sizes = distributed.block_sizes(model.n_particles_total)
+    w_all = distributed.all_gather_rows(w_loc[:, None], sizes=sizes)[:, 0]
+    seed = int(model.rng_shared.integers(0, 2**31 - 1))   # shared stream: same ancestors everywhere
     anc = distributed.resample_ancestors(w_all, seed)
     descr = [(p.program(), float(l)) for p, l in zip(model.particles, model._logml)]
     mine = distributed.exchange_particles(descr, anc)
@@ -519,14 +551,14 @@ def fit_smc(model: GPModel, *, schedule: Sequence[int], n_mcmc: int, n_hmc: int,
     """SMC over data batches (``n_mcmc`` and ``n_hmc`` are required keywords, as in the reference:
     omitting them is an error, test/test_gpconfig.jl:42)."""
     n = model.y.size
-    model._perm = model.rng.permutation(n) if shuffle else np.arange(n)
+    model._perm = model.rng_shared.permutation(n) if shuffle else np.arange(n)
     P = num_particles(model)
     for count in schedule:
         count = int(min(count, n))
         if count <= model.n_obs:
             continue
         lm = _refresh_logml(model, count)
-        model.log_weights = model.log_weights + (lm - model._logml)
+        model.log_weights = _advance_weights(model.log_weights, lm, model._logml)
         model._logml = lm
         model.n_obs = count
         resampled = maybe_resample(model, P / 2.0 if adaptive_resampling else float("inf"))
@@ -534,6 +566,29 @@ def fit_smc(model: GPModel, *, schedule: Sequence[int], n_mcmc: int, n_hmc: int,
             mcmc_structure(model, n_mcmc, n_hmc, hmc_config, biased)
         if verbose:
             print(f"[fit_smc] n_obs={count} ess={effective_sample_size(model):.2f}")
+
+
+def _advance_weights(logw, lm_new, lm_old):
+    """log-weights after an incremental weight update.  A particle whose factorisation failed has
+    logml = -inf; twice in a row that would be -inf - (-inf) = NaN and poison the whole ensemble
+    through the normalisation, so a dead particle simply stays dead (-inf)."""
+    inc = np.where(np.isneginf(lm_new), -np.inf, lm_new - lm_old)
+    out = logw + inc
+    return np.where(np.isnan(out), -np.inf, out)
+
+
+def check_horizon(n_obs: int, d: int, m: int) -> None:
+    """The library carries the appended and forecast points of a query as at most NGP_MAX_AUX
+    rows beside the factor: (n mod 64) + d + m + 1 <= NGP_MAX_AUX (include/ngp.h).  The reference
+    has no such limit; say so clearly instead of surfacing 'problem exceeds a library limit'."""
+    from ._abi import NGP_MAX_AUX
+    room = NGP_MAX_AUX - (n_obs % 64) - d - 1
+    if m > room:
+        raise ValueError(
+            f"forecast horizon of {m} dates is too long for one call: with {n_obs} observations"
+            + (f" and {d} appended points" if d else "")
+            + f" at most {max(room, 0)} forecast dates fit (NGP_MAX_AUX = {NGP_MAX_AUX} rows beside "
+            "the factor; split the dates over several calls)")
 
 
 def add_data(model: GPModel, ds, y) -> None:
@@ -550,7 +605,7 @@ def add_data(model: GPModel, ds, y) -> None:
     model.y = np.concatenate([model.y, y])
     model._perm = np.concatenate([model._perm, np.arange(n_old, n_old + y.size)])
     lm = _refresh_logml(model, n_old + y.size)
-    model.log_weights = model.log_weights + (lm - model._logml)
+    model.log_weights = _advance_weights(model.log_weights, lm, model._logml)
     model._logml = lm
     model.n_obs = n_old + y.size
 
@@ -599,6 +654,7 @@ class MixtureMVN:
 def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
     t, y = model._obs()
     t_new = model.ds_transform.apply(to_days(list(ds)))
+    check_horizon(t.size, 0, t_new.size)
     fac = model._factor()
     if fac is not None:
         mu, sigma, _, info = fac.predict(t_new, noise_on_new)
@@ -612,8 +668,11 @@ def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
     covs = sigma / (s * s)
     w, _ = _normalized_weights(model)
     if distributed.world()[1] > 1:   # every rank returns the full mixture
-        means = distributed.all_gather_rows(means)
-        covs = distributed.all_gather_rows(covs.reshape(covs.shape[0], -1)).reshape(
+        sizes = distributed.block_sizes(model.n_particles_total)
+        means = distributed.all_gather_rows(means, sizes=sizes)
+        covs = distributed.all_gather_rows(covs.reshape(covs.shape[0], -1), sizes=sizes).reshape(
             (-1,) + covs.shape[1:])
-        w = distributed.all_gather_rows(w[:, None])[:, 0]
-    return MixtureMVN(means, covs, w, model.rng, getattr(model._eng(), "mixture_sample", None))
+        w = distributed.all_gather_rows(w[:, None], sizes=sizes)[:, 0]
+    # shared stream: the same draws on every rank
+    return MixtureMVN(means, covs, w, model.rng_shared,
+                      getattr(model._eng(), "mixture_sample", None))

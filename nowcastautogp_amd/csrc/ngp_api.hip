@@ -1454,20 +1454,23 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
 extern "C" ngp_status ngp_weights_normalize(int32_t P, const double *logw, double *w_norm,
                                             double *ess, double *log_norm) {
     if (P <= 0 || !logw) return NGP_ERR_ARG;
+    // a particle whose factorisation failed carries -inf (or NaN after -inf - -inf): weight 0, it
+    // must not poison the others
     double mx = -INFINITY;
     for (int i = 0; i < P; ++i)
-        if (logw[i] > mx) mx = logw[i];
+        if (std::isfinite(logw[i]) && logw[i] > mx) mx = logw[i];
     if (!(mx > -INFINITY)) {
         if (ess) *ess = NAN;
         if (log_norm) *log_norm = -INFINITY;
         if (w_norm) for (int i = 0; i < P; ++i) w_norm[i] = NAN;
         return NGP_OK;
     }
+    auto e = [&](int i) { return std::isfinite(logw[i]) ? std::exp(logw[i] - mx) : 0.0; };
     double sum = 0.0;
-    for (int i = 0; i < P; ++i) sum += std::exp(logw[i] - mx);
+    for (int i = 0; i < P; ++i) sum += e(i);
     double sq = 0.0;
     for (int i = 0; i < P; ++i) {
-        const double w = std::exp(logw[i] - mx) / sum;
+        const double w = e(i) / sum;
         if (w_norm) w_norm[i] = w;
         sq += w * w;
     }

@@ -84,6 +84,17 @@ def all_gather_rows(x: np.ndarray, device=None, sizes: Optional[np.ndarray] = No
     return np.concatenate([full[r * nmax:r * nmax + int(sizes[r])] for r in range(len(sizes))])
 
 
+def broadcast_int(v: int) -> int:
+    """rank 0's value of a non-negative integer < 2^62 on every rank (three exact 21-bit pieces
+    through the same all-gather the weights use)."""
+    d = _dist()
+    if d is None or d.get_world_size() == 1:
+        return int(v)
+    parts = np.array([[float((int(v) >> (21 * k)) & 0x1FFFFF) for k in range(3)]])
+    got = all_gather_rows(parts, sizes=np.ones(d.get_world_size(), dtype=np.int64))[0]
+    return int(got[0]) | (int(got[1]) << 21) | (int(got[2]) << 42)
+
+
 def block_sizes(P_total: int, size: Optional[int] = None) -> np.ndarray:
     """Rows per rank of the block partition ``shard`` makes (no communication)."""
     size = world()[1] if size is None else size

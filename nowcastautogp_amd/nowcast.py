@@ -92,10 +92,11 @@ def make_and_fit_model(data: TData, *, n_particles: int = 1, smc_data_proportion
                         "(forwarded to fit_smc)")
     config = config if config is not None else GPConfig()
     n_train = len(data.y)
-    y_fit = _stabilize_for_fit(data.y, flat_threshold=flat_threshold,
-                               rng=np.random.default_rng(seed))
+    streams = autogp.make_streams(seed)
+    # the jitter comes from the stream every rank shares: all ranks must fit the same series
+    y_fit = _stabilize_for_fit(data.y, flat_threshold=flat_threshold, rng=streams[0])
     model = GPModel(data.ds, y_fit, n_particles=n_particles, config=config, engine=engine,
-                    seed=seed)
+                    seed=seed, _streams=streams)
     effective = max(smc_data_proportion, 1.0 / n_train)
     schedule = autogp.Schedule.linear_schedule(n_train, effective)
     autogp.fit_smc(model, schedule=schedule, n_mcmc=n_mcmc, n_hmc=n_hmc, **kwargs)
@@ -151,6 +152,12 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
     results = []
     for nc in nowcasts:   # the reference's per-scenario task, sequential here
         m = GPModel.from_dict(copy.deepcopy(base), engine=base_model.engine)
+        # every scenario is its own task with its own randomness in the reference
+        # (src/forecasting.jl:131-133); a clone that kept the snapshot's stream would repeat the
+        # first scenario's draws.  Splitting also advances the base model's streams, so a second
+        # call differs from the first.
+        m.rng = autogp.child_stream(base_model.rng)
+        m.rng_shared = autogp.child_stream(base_model.rng_shared)
         autogp.add_data(m, nc.ds, nc.y)
         autogp.maybe_resample(m, ess_threshold * autogp.num_particles(m))
         if n_mcmc > 0 and n_hmc > 0:
@@ -173,6 +180,7 @@ def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transform
     y_add = np.stack([model.y_transform.apply(np.asarray(nc.y, dtype=np.float64))
                       for nc in nowcasts])
     t_new = model.ds_transform.apply(autogp.to_days(dates))
+    autogp.check_horizon(t.size, t_add.size, t_new.size)
     fac = model._factor()
     if fac is not None:
         out = fac.nowcast(t_add, y_add, t_new, True)
@@ -184,7 +192,7 @@ def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transform
     s, b = model.y_transform.slope, model.y_transform.intercept
     covs = out["sigma"] / (s * s)
     P = len(model.particles)
-    rng = model.rng
+    rng = model.rng_shared
     D = len(nowcasts)
     sampler = getattr(model._eng(), "mixture_sample", None)
     if sampler is not None and len(dates) > 0:

@@ -417,19 +417,20 @@ int ngpo_logml_grad(const ngp_spec *s, const ngp_kernel *k, int n, const double 
 int ngpo_weights_normalize(int P, const double *logw, double *w_norm, double *ess,
                            double *log_norm) {
     if (P <= 0 || !logw) return NGP_ERR_ARG;
+    /* non-finite entries (a failed particle: -inf, or NaN) carry weight 0 */
     double mx = -INFINITY;
-    for (int i = 0; i < P; ++i) if (logw[i] > mx) mx = logw[i];
-    if (!(mx > -INFINITY)) { /* all -inf or NaN: undefined weights */
+    for (int i = 0; i < P; ++i) if (isfinite(logw[i]) && logw[i] > mx) mx = logw[i];
+    if (!(mx > -INFINITY)) { /* nothing finite: undefined weights */
         if (ess) *ess = NAN;
         if (log_norm) *log_norm = -INFINITY;
         if (w_norm) for (int i = 0; i < P; ++i) w_norm[i] = NAN;
         return NGP_OK;
     }
     double sum = 0.0;
-    for (int i = 0; i < P; ++i) sum += exp(logw[i] - mx);
+    for (int i = 0; i < P; ++i) sum += isfinite(logw[i]) ? exp(logw[i] - mx) : 0.0;
     double sq = 0.0;
     for (int i = 0; i < P; ++i) {
-        double w = exp(logw[i] - mx) / sum;
+        double w = (isfinite(logw[i]) ? exp(logw[i] - mx) : 0.0) / sum;
         if (w_norm) w_norm[i] = w;
         sq += w * w;
     }

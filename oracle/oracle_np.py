@@ -188,8 +188,9 @@ def logml_grad_fd(program, t, y, spec=None, rel=1e-6):
 
 def weights_normalize(logw):
     logw = np.asarray(logw, dtype=np.float64)
-    mx = logw.max()
-    e = np.exp(logw - mx)
+    ok = np.isfinite(logw)             # a failed particle (-inf / NaN) carries weight 0
+    mx = logw[ok].max()
+    e = np.where(ok, np.exp(np.where(ok, logw, mx) - mx), 0.0)
     w = e / e.sum()
     return w, float(1.0 / np.sum(w * w)), float(mx + math.log(e.sum()))
 

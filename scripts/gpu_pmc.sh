@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/${TAG}_write -- $CMD > $R/gpurun_out/${TAG}_write.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA --output-format csv -d $R/gpurun_out/${TAG}_sq -- $CMD > $R/gpurun_out/${TAG}_sq.log 2>&1
 cd $R
-WL=$(tail -1 gpurun_out/${TAG}_fetch.log)
+WL=$(grep "^items" gpurun_out/${TAG}_fetch.log | tail -1)
 python3 scripts/pmc_to_json.py $TAG $CFG "scripts/pmc_workload.py $CFG $PART: $WL" | tee gpurun_out/${TAG}.txt
 python3 - <<PY | tee -a gpurun_out/${TAG}.txt
 import csv, glob, collections

@@ -44,7 +44,10 @@ try:
     commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
     commit = None
+import re
+m = re.search(r"items (\d+)", workload)
 out = {"config": config, "workload": workload, "commit": commit,
+       "items": int(m.group(1)) if m else None,   # items every launch of the profiled job covered
        "calibration": {"kernel": "stream_copy_kernel, 2^30 B read + 2^30 B written per launch",
                        "bytes_per_FETCH_SIZE_unit": cal_r, "bytes_per_WRITE_SIZE_unit": cal_w,
                        "guide_expectation": "2048 (1 KiB x 2, gfx950 halving) and 1024"},
