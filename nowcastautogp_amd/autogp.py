@@ -181,30 +181,29 @@ class Particle:
 
 
 def make_streams(seed: Optional[int] = None):
-    """(shared, local) random streams of a model.
+    """(root, shared): the random streams of a model hang off one integer ``root``.
 
     ``shared`` is the SAME stream on every rank (data-annealing permutation, flat-series jitter,
-    resampling ancestors, mixture draws): it is seeded from ``seed``, or — ``seed is None`` — from
-    rank 0's entropy, broadcast.  ``local`` differs per rank (particle initialisation, structure
-    and HMC moves): a rank that shared it would hold a copy of rank 0's particles.  With one rank
-    both still exist, so a run does not change its draws when it is sharded."""
-    rank, world = distributed.world()
+    resampling ancestors, mixture draws), seeded from ``seed`` or — ``seed is None`` — from rank
+    0's entropy, broadcast.  Everything that concerns ONE particle (its initial tree, its
+    structure proposals, its HMC momenta and accept draws) comes from that particle's own stream,
+    ``particle_stream(root, generation, global index)``: a particle therefore sees the same
+    randomness whichever rank owns it, and a sharded run reproduces the single-rank run."""
+    world = distributed.world()[1]
     if seed is None:
-        root = int(np.random.SeedSequence().generate_state(2, dtype=np.uint32).astype(np.uint64)
-                   @ np.array([1, 2**31], dtype=np.uint64)) % (2**62)
+        st = np.random.SeedSequence().generate_state(2, dtype=np.uint32)
+        root = (int(st[0]) | (int(st[1]) << 31)) % (2**62)
         if world > 1:
             root = distributed.broadcast_int(root)
     else:
         root = int(seed)
-    shared = np.random.Generator(np.random.PCG64(np.random.SeedSequence([root, 0])))
-    local = np.random.Generator(np.random.PCG64(np.random.SeedSequence([root, 1, rank])))
-    return shared, local
+    return root, np.random.Generator(np.random.PCG64(np.random.SeedSequence([root, 0])))
 
 
-def child_stream(rng: np.random.Generator) -> np.random.Generator:
-    """An independent stream split off ``rng`` (which advances): the per-scenario clones of
-    forecast_with_nowcasts each get their own, as the reference's tasks do."""
-    return np.random.Generator(np.random.PCG64(int(rng.integers(0, 2**63 - 1))))
+def particle_stream(root: int, generation: int, index: int) -> np.random.Generator:
+    """Stream of the particle with GLOBAL index ``index``; ``generation`` counts resamplings (the
+    copies of a resampled ancestor must not share its future)."""
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence([root, 1, generation, index])))
 
 
 class GPModel:
@@ -233,13 +232,15 @@ class GPModel:
         self.ds_transform = _ds_transform(self.days)
         self.y_transform = _y_transform(self.y)
         self.depth_cap = depth_cap
-        self.rng_shared, self.rng = _streams if _streams is not None else make_streams(seed)
+        self._root, self.rng_shared = _streams if _streams is not None else make_streams(seed)
+        self._gen = 0
         self.n_particles_total = int(n_particles)
         sl = distributed.shard(self.n_particles_total)
         nloc = sl.stop - sl.start
+        self.prng = [particle_stream(self._root, 0, i) for i in range(sl.start, sl.stop)]
         self.particles: List[Particle] = [
-            Particle(gp.sample_tree(self.rng, self.config, depth_cap=depth_cap),
-                     gp.sample_noise(self.rng, self.config)) for _ in range(nloc)]
+            Particle(gp.sample_tree(r, self.config, depth_cap=depth_cap),
+                     gp.sample_noise(r, self.config)) for r in self.prng]
         self.log_weights = np.zeros(nloc)
         self.n_obs = 0                      # observations absorbed so far (data annealing)
         self._perm = np.arange(y.size)
@@ -304,7 +305,8 @@ class GPModel:
                                noise=p.noise) for p in self.particles],
             "log_weights": self.log_weights.copy(), "n_obs": self.n_obs,
             "perm": self._perm.copy(), "logml": self._logml.copy(),
-            "rng_state": copy.deepcopy(self.rng.bit_generator.state),
+            "rng_root": self._root, "rng_generation": self._gen,
+            "rng_particle_states": [copy.deepcopy(r.bit_generator.state) for r in self.prng],
             "rng_shared_state": copy.deepcopy(self.rng_shared.bit_generator.state),
         }
 
@@ -321,11 +323,21 @@ class GPModel:
         self.n_obs = int(d["n_obs"])
         self._perm = np.array(d["perm"])
         self._logml = np.array(d["logml"], float)
-        self.rng = np.random.Generator(np.random.PCG64())
-        self.rng.bit_generator.state = copy.deepcopy(d["rng_state"])
+        self._root, self._gen = int(d["rng_root"]), int(d["rng_generation"])
+        self.prng = []
+        for st in d["rng_particle_states"]:
+            r = np.random.Generator(np.random.PCG64())
+            r.bit_generator.state = copy.deepcopy(st)
+            self.prng.append(r)
         self.rng_shared = np.random.Generator(np.random.PCG64())
-        self.rng_shared.bit_generator.state = copy.deepcopy(d.get("rng_shared_state",
-                                                                  d["rng_state"]))
+        self.rng_shared.bit_generator.state = copy.deepcopy(d["rng_shared_state"])
+
+    def reseed(self, root: int) -> None:
+        """Fresh streams for a clone (forecast_with_nowcasts gives every scenario its own root)."""
+        self._root, self._gen = int(root), 0
+        lo = distributed.shard(self.n_particles_total).start
+        self.prng = [particle_stream(self._root, 0, lo + i) for i in range(len(self.particles))]
+        self.rng_shared = np.random.Generator(np.random.PCG64(np.random.SeedSequence([self._root, 0])))
 
     @classmethod
     def from_dict(cls, d: dict, engine=None) -> "GPModel":
@@ -366,6 +378,9 @@ def maybe_resample(model: GPModel, ess_threshold: float) -> bool:
     model.particles = [Particle(gp.from_program(pr[0], pr[1]), float(pr[2])) for pr, _ in mine]
     model._logml = np.array([l for _, l in mine])
     model.log_weights = np.zeros(len(mine))
+    model._gen += 1      # copies of one ancestor must not share its future draws
+    lo = distributed.shard(model.n_particles_total).start
+    model.prng = [particle_stream(model._root, model._gen, lo + i) for i in range(len(mine))]
     return True
 
 
@@ -394,9 +409,10 @@ def _nodes(tree: gp.Node):
 def _structure_move(model: GPModel, t, y):
     """Subtree-regeneration Metropolis-Hastings: pick a node uniformly, redraw its subtree from
     the prior; accept with min(1, L'/L * |T|/|T'|)."""
-    rng, cfg = model.rng, model.config
+    cfg = model.config
     props, idx = [], []
     for k, p in enumerate(model.particles):
+        rng = model.prng[k]
         new = gp.clone(p.tree)
         nodes = _nodes(new)
         nd, depth, parent, side = nodes[int(rng.integers(len(nodes)))]
@@ -417,7 +433,7 @@ def _structure_move(model: GPModel, t, y):
         if bad or not np.isfinite(l1):
             continue
         log_a = (l1 - model._logml[k]) + math.log(model.particles[k].tree.size() / tr.size())
-        if math.log(rng.random()) < log_a:
+        if math.log(model.prng[k].random()) < log_a:
             model.particles[k].tree = tr
             model._logml[k] = float(l1)
             acc += 1
@@ -440,7 +456,7 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
     U(z) = -log p(y | theta(z)) + |z|^2 / 2, gradient through the engine's logml gradient.
     All particles move together: the latents live in one flat vector (``sl[k]`` is particle k's
     slice), every leapfrog stage is one engine call and a handful of numpy operations."""
-    rng, prior = model.rng, model.config.prior
+    prior = model.config.prior
     fixed_noise = model.config.noise is not None
     P = len(model.particles)
     z0, kinds = _latents(model)
@@ -490,7 +506,7 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
 
     z0 = np.concatenate(z0)
     U0, dU, _ = potential(z0)
-    mom = rng.standard_normal(z0.size)
+    mom = np.concatenate([model.prng[k].standard_normal(int(sizes[k])) for k in range(P)])
     if fixed_noise:
         mom[last] = 0.0
     H0 = U0 + 0.5 * sums(mom * mom)
@@ -506,7 +522,8 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
     th_new, _ = gp.transform_flat(z, codes, prior)
     acc = 0
     for k in range(P):
-        if np.isfinite(H1[k]) and math.log(rng.random()) < H0[k] - H1[k]:
+        u = model.prng[k].random()      # drawn for every particle: the stream does not depend on H
+        if np.isfinite(H1[k]) and math.log(u) < H0[k] - H1[k]:
             th = th_new[sl[k]]
             model.particles[k].tree = gp.from_program(ops[k], th[:-1])
             model.particles[k].noise = float(th[-1])
@@ -572,8 +589,9 @@ def _advance_weights(logw, lm_new, lm_old):
     """log-weights after an incremental weight update.  A particle whose factorisation failed has
     logml = -inf; twice in a row that would be -inf - (-inf) = NaN and poison the whole ensemble
     through the normalisation, so a dead particle simply stays dead (-inf)."""
-    inc = np.where(np.isneginf(lm_new), -np.inf, lm_new - lm_old)
-    out = logw + inc
+    with np.errstate(invalid="ignore"):
+        inc = np.where(np.isneginf(lm_new), -np.inf, lm_new - lm_old)
+        out = logw + inc
     return np.where(np.isnan(out), -np.inf, out)
 
 

@@ -94,7 +94,7 @@ def make_and_fit_model(data: TData, *, n_particles: int = 1, smc_data_proportion
     n_train = len(data.y)
     streams = autogp.make_streams(seed)
     # the jitter comes from the stream every rank shares: all ranks must fit the same series
-    y_fit = _stabilize_for_fit(data.y, flat_threshold=flat_threshold, rng=streams[0])
+    y_fit = _stabilize_for_fit(data.y, flat_threshold=flat_threshold, rng=streams[1])
     model = GPModel(data.ds, y_fit, n_particles=n_particles, config=config, engine=engine,
                     seed=seed, _streams=streams)
     effective = max(smc_data_proportion, 1.0 / n_train)
@@ -156,8 +156,7 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
         # (src/forecasting.jl:131-133); a clone that kept the snapshot's stream would repeat the
         # first scenario's draws.  Splitting also advances the base model's streams, so a second
         # call differs from the first.
-        m.rng = autogp.child_stream(base_model.rng)
-        m.rng_shared = autogp.child_stream(base_model.rng_shared)
+        m.reseed(int(base_model.rng_shared.integers(0, 2**62)))
         autogp.add_data(m, nc.ds, nc.y)
         autogp.maybe_resample(m, ess_threshold * autogp.num_particles(m))
         if n_mcmc > 0 and n_hmc > 0:

@@ -74,10 +74,12 @@ def check_required_keywords_and_config(engine):
     model = nc.make_and_fit_model(data, engine=engine, config=nc.GPConfig(prior=prior), seed=5,
                                   **FAST)
     assert model.config.prior["period"]["mu"] == 0.0     # :31-34
-    # only Linear / Periodic leaves may appear under the restricted grammar
-    for p in fitted(engine, config=cfg, seed=6).particles:
-        ops, _ = gp.to_program(p.tree)
-        assert set(ops.tolist()) <= {gp.LINEAR, gp.PERIODIC, gp.PLUS, gp.TIMES}
+    # changepoints = false: no ChangePoint node may appear, whatever the seed (leaves below the
+    # depth cap still come from node_dist_nocp, so other leaf kinds are legal)
+    for seed in (6, 7, 8):
+        for p in fitted(engine, config=cfg, seed=seed, n_particles=3).particles:
+            ops, _ = gp.to_program(p.tree)
+            assert gp.CHANGE_POINT not in set(ops.tolist())
 
 
 def check_flat_and_constant_series(engine):

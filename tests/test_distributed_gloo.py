@@ -66,6 +66,64 @@ def test_weight_normalisation_and_resampling_over_two_ranks():
     assert abs(res[0][6] - oracle_np.weights_normalize(logw_all[:, 0])[1]) < 1e-12
 
 
+def _fit_and_predict(P, seed):
+    """make_and_fit_model -> forced maybe_resample -> mcmc -> predict_mvn, on whatever process
+    group is (or is not) initialised; returns the FULL mixture and this rank's programs."""
+    from nowcastautogp_amd import autogp
+    from nowcastautogp_amd import nowcast as nc
+    from tests import mirror_contracts as mc
+    from tests.engine_oracle import OracleEngine
+    data = nc.create_transformed_data(mc.days(0, 20), mc.series20(), transformation=lambda v: v)
+    model = nc.make_and_fit_model(data, engine=OracleEngine(), seed=seed, n_particles=P, n_mcmc=2,
+                                  n_hmc=1)
+    model.log_weights = model.log_weights - 3.0 * np.arange(len(model.particles))
+    assert autogp.maybe_resample(model, float(P))          # ESS < P: always resamples
+    autogp.mcmc_structure(model, 1, 1)
+    mix = autogp.predict_mvn(model, mc.days(20, 24))
+    draws = mix.rand(7)
+    return dict(means=mix.means, covs=mix.covs, w=mix.weights, draws=draws,
+                programs=[(p.program()[0].tolist(), p.program()[1].tolist(), p.noise)
+                          for p in model.particles], lw=model.log_weights.copy())
+
+
+def _worker_model(rank, world, port, q, P, seed):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank, _fit_and_predict(P, seed)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_sharded_model_reproduces_the_single_rank_model():
+    """GPModel sharding (ragged: 5 particles over 2 ranks), fit_smc, maybe_resample with the
+    descriptor exchange, structure + HMC moves and predict_mvn's gather, end to end over gloo:
+    every particle has its own random stream keyed by its global index, so the two-rank run must
+    give the single-rank mixture (this path had never been executed)."""
+    P, seed = 5, 3
+    ref = _fit_and_predict(P, seed)                      # this process: no process group
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_model, args=(r, world, port, q, P, seed))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [len(res[r]["programs"]) for r in range(world)] == [3, 2]
+    assert res[0]["programs"] + res[1]["programs"] == ref["programs"]
+    for r in range(world):                               # every rank holds the FULL mixture
+        assert np.allclose(res[r]["means"], ref["means"], rtol=1e-12, atol=1e-12)
+        assert np.allclose(res[r]["covs"], ref["covs"], rtol=1e-12, atol=1e-12)
+        assert np.allclose(res[r]["w"], ref["w"], rtol=1e-13)
+        assert np.allclose(res[r]["draws"], ref["draws"], rtol=1e-10, atol=1e-10)
+    assert np.array_equal(np.concatenate([res[0]["lw"], res[1]["lw"]]), ref["lw"])
+
+
 def test_shard_partition_covers_everything():
     from nowcastautogp_amd.distributed import shard
     for P in (1, 7, 64, 257):

@@ -147,3 +147,58 @@ def test_transform_flat_equals_the_per_particle_transform():
     ref = [gp.transform(z, kd, cfg.prior) for z, kd in zip(zs, kinds)]
     assert np.allclose(th, np.concatenate([r[0] for r in ref]), rtol=1e-14, atol=0)
     assert np.allclose(dth, np.concatenate([r[1] for r in ref]), rtol=1e-13, atol=1e-300)
+
+
+def test_identical_scenarios_get_independent_draws_and_calls_differ(eng):
+    """the per-scenario fallback rebuilt every clone from one snapshot, RNG state
+    included, so D scenarios behaved like one set of draws repeated D times."""
+    model = mc.fitted(eng, seed=21, n_particles=2)
+    scen = nc.create_nowcast_data([[101.0, 102.0]] * 3, mc.days(20, 22))   # three IDENTICAL scenarios
+    dates = mc.days(22, 25)
+    # n_hmc > 0 forces the per-scenario path (the reference's task per scenario)
+    a = nc.forecast_with_nowcasts(model, scen, dates, 6, n_hmc=1)
+    assert a.shape == (3, 18)
+    blocks = [a[:, 6 * k:6 * (k + 1)] for k in range(3)]
+    assert not np.allclose(blocks[0], blocks[1]) and not np.allclose(blocks[1], blocks[2])
+    b = nc.forecast_with_nowcasts(model, scen, dates, 6, n_hmc=1)
+    assert not np.allclose(a, b)            # the base model's streams advanced
+
+
+def test_a_dead_particle_stays_dead_and_does_not_poison_the_ensemble():
+    """a particle failing twice gave -inf - (-inf) = NaN in the weight update."""
+    from nowcastautogp_amd import _lib
+    lw = autogp._advance_weights(np.array([0.0, -np.inf, -1.0]),
+                                 np.array([-3.0, -np.inf, -2.5]), np.array([-2.0, -np.inf, -2.0]))
+    assert lw[0] == -1.0 and np.isneginf(lw[1]) and lw[2] == -1.5
+    w, ess, ln = _lib.weights_normalize(lw)            # host-side C entry point: no GPU needed
+    assert w[1] == 0.0 and abs(w.sum() - 1.0) < 1e-15 and 1.0 < ess <= 2.0 and np.isfinite(ln)
+    w, ess, ln = _lib.weights_normalize(np.array([np.nan, 0.0, 0.0]))
+    assert w[0] == 0.0 and abs(ess - 2.0) < 1e-12
+
+
+def test_an_engine_that_fails_twice_leaves_finite_weights():
+    class Failing:
+        """particle 0's factorisation fails on every call"""
+        def __init__(self):
+            self.e = OracleEngine()
+
+        def logml(self, programs, t, y):
+            lm, info = self.e.logml(programs, t, y)
+            lm, info = lm.copy(), info.copy()
+            lm[0], info[0] = np.nan, 3
+            return lm, info
+
+        def __getattr__(self, name):
+            return getattr(self.e, name)
+
+    data = nc.create_transformed_data(mc.days(0, 20), mc.series20(), transformation=lambda v: v)
+    model = nc.make_and_fit_model(data, engine=Failing(), seed=5, n_particles=3, n_mcmc=0, n_hmc=0)
+    w, ess = autogp._normalized_weights(model)
+    assert np.isfinite(w).all() and w[0] == 0.0 and np.isfinite(ess)
+
+
+def test_too_long_a_horizon_is_a_clear_error(eng):
+    model = mc.fitted(eng, seed=22)
+    with pytest.raises(ValueError, match="forecast horizon"):
+        autogp.predict_mvn(model, mc.days(20, 20 + 400))
+    assert autogp.predict_mvn(model, mc.days(20, 20 + 150)).means.shape[1] == 150
