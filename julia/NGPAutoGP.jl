@@ -2,11 +2,13 @@
 # NowcastAutoGP calls (src/make_and_fit_model.jl:84-91, src/forecasting.jl:46-155).
 #
 # STATUS: written against include/ngp.h, NEVER EXECUTED — no `julia` binary exists in the build
-# container or on the GPU box.  The Python package `nowcastautogp_amd` is the executed, tested
-# host-side mirror of the same surface over the same C-ABI (ctypes); this file is the reference-
-# language counterpart a maintainer starts from.  Struct layouts below mirror the header byte for
-# byte (all fields naturally aligned, no padding surprises: Int32 x4 + Float64; Int32 x2 + 2 ptr +
-# Float64).
+# container or on the GPU box.  What IS checked mechanically (tests/test_julia_shim.py, CPU suite):
+# every `ccall((:ngp_…` below against the header (symbol, arity, C type of every argument and of
+# the result), the field lists of the mirrored structs, the presence of the thirteen AutoGP surface
+# symbols the reference touches (SURVEY.md Appendix A), and that `Dict(::GPModel)` / `GPModel(::Dict)`
+# use the keys of the version-1 wire format (nowcastautogp_amd/wire.py).  The Python package
+# `nowcastautogp_amd` is the executed, tested host-side mirror of the same surface over the same
+# C-ABI; the sampler moves here restate its design (nowcastautogp_amd/autogp.py).
 module NGPAutoGP
 
 using Dates, Random, LinearAlgebra
@@ -14,13 +16,18 @@ using Dates, Random, LinearAlgebra
 const LIBNGP = get(ENV, "LIBNGP", joinpath(@__DIR__, "..", "nowcastautogp_amd", "libngp.so"))
 
 # ---- include/ngp.h mirrors --------------------------------------------------------------------
-struct NgpSpec
+struct NgpSpec              # ngp_spec
     se_form::Int32
     periodic_form::Int32
     cp_form::Int32
-    reserved::Int32
+    precision::Int32
     jitter::Float64
+    mixed_tau::Float64
+    refine_tol::Float64
+    refine_max::Int32
+    reserved::Int32
 end
+default_spec(; precision = 0) = NgpSpec(0, 0, 0, precision, 1.0e-5, 1.0e-6, 1.0e-9, 3, 0)
 
 struct NgpKernel            # ngp_kernel
     n_ops::Int32
@@ -51,6 +58,19 @@ mutable struct Context
     end
 end
 
+function set_spec(c::Context, s::NgpSpec)
+    check(ccall((:ngp_set_spec, LIBNGP), Int32, (Ptr{Cvoid}, Ref{NgpSpec}), c.h, Ref(s)),
+          "ngp_set_spec")
+end
+function get_spec(c::Context)
+    r = Ref(default_spec())
+    check(ccall((:ngp_get_spec, LIBNGP), Int32, (Ptr{Cvoid}, Ref{NgpSpec}), c.h, r), "ngp_get_spec")
+    return r[]
+end
+
+const _default_ctx = Ref{Union{Nothing, Context}}(nothing)
+default_context() = (_default_ctx[] === nothing && (_default_ctx[] = Context(0)); _default_ctx[])
+
 # One particle's kernel as the postfix arrays the ABI carries; opcodes follow
 # AutoGP.GP.GPConfig (Constant=1 ... ChangePoint=8).
 struct Program
@@ -62,6 +82,13 @@ end
 "GC-safe view of a vector of programs as an array of ngp_kernel (keep `progs` alive via GC.@preserve)."
 kernels(progs::Vector{Program}) = [NgpKernel(length(p.ops), length(p.params), pointer(p.ops),
                                              pointer(p.params), p.noise) for p in progs]
+
+function kernel_check(p::Program)
+    GC.@preserve p begin
+        k = Ref(NgpKernel(length(p.ops), length(p.params), pointer(p.ops), pointer(p.params), p.noise))
+        return ccall((:ngp_kernel_check, LIBNGP), Int32, (Ref{NgpKernel},), k) == 0
+    end
+end
 
 # ---- entry points -------------------------------------------------------------------------------
 function logml_batch(c::Context, progs::Vector{Program}, t::Vector{Float64}, y::VecOrMat{Float64})
@@ -201,42 +228,331 @@ function weights_normalize(logw::Vector{Float64})
 end
 
 "info[b] > 0  =>  PosDefException(info[b]), as the reference surfaces it (src/make_and_fit_model.jl:6-8)."
-raise_if_not_posdef(info) = (k = findfirst(!=(0), info); k === nothing || throw(PosDefException(info[k])))
+raise_if_not_posdef(info) = (k = findfirst(>(0), info); k === nothing || throw(PosDefException(info[k])))
 
-# ---- AutoGP surface (thin; the SMC orchestration is the one in nowcastautogp_amd/autogp.py) -------
+# ---- kernel grammar: AutoGP.GP.GPConfig (src/NowcastAutoGP.jl:9; defaults as printed in
+#      docs/src/vignettes/setting-priors.md:228-245) ------------------------------------------------
+module GP
+Base.@kwdef mutable struct GPConfig
+    Constant::Int = 1
+    Linear::Int = 2
+    SquaredExponential::Int = 3
+    GammaExponential::Int = 4
+    Periodic::Int = 5
+    Plus::Int = 6
+    Times::Int = 7
+    ChangePoint::Int = 8
+    node_dist_leaf::Vector{Float64} = [0.0, 1 / 3, 0.0, 1 / 3, 1 / 3]
+    node_dist_nocp::Vector{Float64} = [0.0, 3 / 14, 0.0, 3 / 14, 3 / 14, 5 / 28, 5 / 28]
+    node_dist_cp::Vector{Float64} = [0.0, 3 / 14, 0.0, 3 / 14, 3 / 14, 1 / 7, 1 / 7, 1 / 14]
+    max_branch::Int = 2
+    max_depth::Int = -1
+    changepoints::Bool = true
+    noise::Union{Nothing, Float64} = nothing
+    prior::Dict{Symbol, Dict{Symbol, Float64}} = Dict(
+        :gamma => Dict(:mu => 0.0, :sigma => 1.0),
+        :period => Dict(:mu => -1.5, :sigma => 1.0),
+        :wildcard => Dict(:mu => -1.5, :sigma => 1.0))
+end
+end # module GP
+const GPConfig = GP.GPConfig
+
+const N_PARAMS = (1, 3, 2, 3, 3, 0, 0, 2)               # per opcode 1..8
+# kind of every parameter, per opcode: :real, :unit, :gamma, :period, :wildcard
+const PARAM_KINDS = ((:wildcard,), (:real, :wildcard, :wildcard), (:wildcard, :wildcard),
+                     (:wildcard, :gamma, :wildcard), (:wildcard, :period, :wildcard), (), (),
+                     (:unit, :wildcard))
+
+mutable struct Node
+    op::Int
+    params::Vector{Float64}
+    left::Union{Nothing, Node}
+    right::Union{Nothing, Node}
+end
+isleaf(n::Node) = n.op < 6
+treesize(n::Node) = isleaf(n) ? 1 : 1 + treesize(n.left) + treesize(n.right)
+
+_sigmoid(x) = x >= 0 ? 1 / (1 + exp(-min(x, 700.0))) : (e = exp(max(x, -700.0)); e / (1 + e))
+"latent z ~ N(0,1) -> parameter and d theta / d z (nowcastautogp_amd/gp.py transform)"
+function transform(z::Float64, kind::Symbol, prior)
+    if kind === :real
+        return z, 1.0
+    elseif kind === :unit
+        s = _sigmoid(z); return s, s * (1 - s)
+    elseif kind === :gamma
+        pr = prior[:gamma]; s = _sigmoid(pr[:mu] + pr[:sigma] * z)
+        return 2s, 2s * (1 - s) * pr[:sigma]
+    else
+        pr = kind === :period ? prior[:period] : prior[:wildcard]
+        v = exp(clamp(pr[:mu] + pr[:sigma] * z, -300.0, 300.0))
+        return v, v * pr[:sigma]
+    end
+end
+function untransform(th::Float64, kind::Symbol, prior)
+    kind === :real && return th
+    kind === :unit && return log(th / (1 - th))
+    if kind === :gamma
+        pr = prior[:gamma]; s = th / 2
+        return (log(s / (1 - s)) - pr[:mu]) / pr[:sigma]
+    end
+    pr = kind === :period ? prior[:period] : prior[:wildcard]
+    return (log(th) - pr[:mu]) / pr[:sigma]
+end
+
+function _categorical(rng, p)
+    u = rand(rng); c = 0.0
+    for (i, pi) in enumerate(p)
+        c += pi
+        u < c && return i
+    end
+    return length(p)
+end
+
+"Draw a kernel tree from the grammar prior (parameters from their priors)."
+function sample_tree(rng, cfg::GPConfig, depth::Int = 1; depth_cap::Int = 6)
+    cap = cfg.max_depth > 0 ? cfg.max_depth : depth_cap
+    dist = depth >= cap ? cfg.node_dist_leaf : (cfg.changepoints ? cfg.node_dist_cp : cfg.node_dist_nocp)
+    op = _categorical(rng, dist)
+    th = [transform(randn(rng), k, cfg.prior)[1] for k in PARAM_KINDS[op]]
+    op < 6 && return Node(op, th, nothing, nothing)
+    l = sample_tree(rng, cfg, depth + 1; depth_cap)
+    r = sample_tree(rng, cfg, depth + 1; depth_cap)
+    return Node(op, th, l, r)
+end
+sample_noise(rng, cfg::GPConfig) =
+    cfg.noise === nothing ? transform(randn(rng), :wildcard, cfg.prior)[1] : cfg.noise
+
+function to_program(n::Node, noise::Float64)
+    ops = Int32[]; params = Float64[]
+    walk(nd) = (isleaf(nd) || (walk(nd.left); walk(nd.right)); push!(ops, nd.op); append!(params, nd.params))
+    walk(n)
+    return Program(ops, params, noise)
+end
+function from_program(p::Program)
+    stack = Node[]; k = 0
+    for op in p.ops
+        np = N_PARAMS[op]; th = p.params[k+1:k+np]; k += np
+        if op < 6
+            push!(stack, Node(op, th, nothing, nothing))
+        else
+            r = pop!(stack); l = pop!(stack)
+            push!(stack, Node(op, th, l, r))
+        end
+    end
+    return only(stack)
+end
+param_kinds(p::Program) = Symbol[k for op in p.ops for k in PARAM_KINDS[op]]
+
+# ---- the AutoGP surface NowcastAutoGP touches (SURVEY.md Appendix A) ----------------------------
 mutable struct GPModel
-    config::Any
+    config::GPConfig
     ds::Vector{Date}
     y::Vector{Float64}
     particles::Vector{Program}
     log_weights::Vector{Float64}
-    logml::Vector{Float64}
+    logml::Vector{Float64}          # log p(y[perm[1:n_obs]] | particle)
+    n_obs::Int
+    perm::Vector{Int}               # data-annealing order (1-based here, 0-based on the wire)
+    ds_slope::Float64               # model time = ds_slope * days + ds_intercept
+    ds_intercept::Float64
+    y_slope::Float64                # model y = y_slope * y + y_intercept
+    y_intercept::Float64
+    depth_cap::Int
+    rng::AbstractRNG
     ctx::Context
 end
 num_particles(m::GPModel) = length(m.particles)
 
-_t(m::GPModel, ds) = (d0 = Dates.value(minimum(m.ds)); d1 = Dates.value(maximum(m.ds));
-                      [(Dates.value(d) - d0) / (d1 - d0) for d in ds])
-_yslope(m::GPModel) = 2 / (maximum(m.y) - minimum(m.y))
-_yscaled(m::GPModel, y) = _yslope(m) .* y .- _yslope(m) * (maximum(m.y) + minimum(m.y)) / 2
+_days(ds) = Float64[Dates.value(d) for d in ds]
 
-function add_data!(m::GPModel, ds::Vector{Date}, y::Vector{Float64})
-    yall = vcat(m.y, y)
-    lm, info = logml_batch(m.ctx, m.particles, _t(m, vcat(m.ds, ds)),
-                           _yslope(m) .* yall .- _yslope(m) * (maximum(m.y) + minimum(m.y)) / 2)
-    raise_if_not_posdef(info)
-    m.log_weights .+= lm .- m.logml
-    m.logml = lm
-    append!(m.ds, ds); append!(m.y, y)
+"AutoGP.GPModel(ds, y; n_particles, config) — src/make_and_fit_model.jl:84-87"
+function GPModel(ds::AbstractVector{<:Dates.TimeType}, y::AbstractVector{<:Real};
+                 n_particles::Int = 8, config::GPConfig = GPConfig(),
+                 ctx::Context = default_context(), rng::AbstractRNG = Random.default_rng(),
+                 depth_cap::Int = 6)
+    length(ds) == length(y) || throw(ArgumentError("ds and y must have the same length"))
+    days = _days(ds); lo, hi = extrema(days); span = hi > lo ? hi - lo : 1.0
+    ylo, yhi = extrema(y)
+    yhi > ylo || throw(PosDefException(1))     # flat series: src/make_and_fit_model.jl:6-8
+    ys = 2 / (yhi - ylo)
+    parts = [to_program(sample_tree(rng, config; depth_cap), sample_noise(rng, config))
+             for _ in 1:n_particles]
+    return GPModel(config, collect(Date, ds), collect(Float64, y), parts, zeros(n_particles),
+                   zeros(n_particles), 0, collect(1:length(y)), 1 / span, -lo / span, ys,
+                   -ys * (yhi + ylo) / 2, depth_cap, rng, ctx)
+end
+
+function _obs(m::GPModel, count::Int = m.n_obs)
+    idx = sort(m.perm[1:count])
+    return m.ds_slope .* _days(m.ds[idx]) .+ m.ds_intercept, m.y_slope .* m.y[idx] .+ m.y_intercept
+end
+
+module Schedule
+"Cumulative observation counts of the data-annealing steps (src/make_and_fit_model.jl:90)."
+function linear_schedule(n::Int, percent::Float64)
+    step = max(1, round(Int, percent * n))
+    out = collect(step:step:n-1)
+    push!(out, n)
+    return out
+end
+end # module Schedule
+
+function _refresh_logml(m::GPModel, count::Int)
+    t, y = _obs(m, count)
+    lm, info = logml_batch(m.ctx, m.particles, t, y)
+    return [(info[i] != 0 || !isfinite(lm[i])) ? -Inf : lm[i] for i in eachindex(lm)]
+end
+_advance(lw, new, old) = [isinf(n) && n < 0 ? -Inf : (v = w + (n - o); isnan(v) ? -Inf : v)
+                          for (w, n, o) in zip(lw, new, old)]
+
+function _structure_move!(m::GPModel, t, y)
+    props = Program[]; idx = Int[]; trees = Node[]
+    for (k, p) in enumerate(m.particles)
+        tree = from_program(p)
+        nodes = Tuple{Node, Int, Union{Nothing, Node}, Symbol}[]
+        walk(nd, depth, parent, side) = (push!(nodes, (nd, depth, parent, side));
+            isleaf(nd) || (walk(nd.left, depth + 1, nd, :left); walk(nd.right, depth + 1, nd, :right)))
+        walk(tree, 1, nothing, :root)
+        nd, depth, parent, side = nodes[rand(m.rng, 1:length(nodes))]
+        sub = sample_tree(m.rng, m.config, depth; depth_cap = m.depth_cap)
+        new = parent === nothing ? sub : (setfield!(parent, side, sub); tree)
+        prog = to_program(new, p.noise)
+        kernel_check(prog) || continue
+        push!(props, prog); push!(idx, k); push!(trees, new)
+    end
+    isempty(props) && return 0
+    lm, info = logml_batch(m.ctx, props, t, y)
+    acc = 0
+    for (j, k) in enumerate(idx)
+        (info[j] != 0 || !isfinite(lm[j])) && continue
+        log_a = (lm[j] - m.logml[k]) + log(length(m.particles[k].ops) / length(props[j].ops))
+        if log(rand(m.rng)) < log_a
+            m.particles[k] = props[j]; m.logml[k] = lm[j]; acc += 1
+        end
+    end
+    return acc
+end
+
+"One HMC transition per particle on the N(0,1) latents of (parameters, noise)."
+function _hmc_move!(m::GPModel, t, y, n_leapfrog::Int, eps::Float64)
+    prior = m.config.prior
+    fixed_noise = m.config.noise !== nothing
+    P = length(m.particles)
+    kinds = [vcat(param_kinds(p), [:wildcard]) for p in m.particles]
+    z0 = [[untransform(th, k, prior) for (th, k) in zip(vcat(p.params, p.noise), kd)]
+          for (p, kd) in zip(m.particles, kinds)]
+    function potential(z)
+        progs = Program[]; dths = Vector{Float64}[]
+        for (p, kd, zk) in zip(m.particles, kinds, z)
+            td = [transform(clamp(isnan(v) ? 0.0 : v, -50.0, 50.0), k, prior) for (v, k) in zip(zk, kd)]
+            th = [clamp(a[1], -1.0e6, 1.0e6) for a in td]
+            push!(dths, [a[2] for a in td])
+            push!(progs, Program(p.ops, th[1:end-1], max(th[end], 1.0e-12)))
+        end
+        lm, grads, info = logml_grad_batch(m.ctx, progs, t, y)
+        U = similar(lm); dU = Vector{Float64}[]
+        for k in 1:P
+            ok = info[k] == 0 && isfinite(lm[k]) && all(isfinite, grads[k])
+            U[k] = ok ? -lm[k] + 0.5 * sum(abs2, z[k]) : Inf
+            g = ok ? (-grads[k] .* dths[k] .+ z[k]) : zeros(length(z[k]))
+            fixed_noise && (g[end] = 0.0)
+            push!(dU, g)
+        end
+        return U, dU, lm, progs
+    end
+    U0, dU, _, _ = potential(z0)
+    mom = [randn(m.rng, length(zk)) for zk in z0]
+    fixed_noise && foreach(p -> (p[end] = 0.0), mom)
+    H0 = [U0[k] + 0.5 * sum(abs2, mom[k]) for k in 1:P]
+    z = deepcopy(z0)
+    pm = [mom[k] .- 0.5 * eps .* dU[k] for k in 1:P]
+    U1 = U0; lm1 = zeros(P); progs1 = m.particles
+    for step in 1:n_leapfrog
+        z = [z[k] .+ eps .* pm[k] for k in 1:P]
+        U1, dU, lm1, progs1 = potential(z)
+        h = step < n_leapfrog ? eps : 0.5 * eps
+        pm = [pm[k] .- h .* dU[k] for k in 1:P]
+    end
+    acc = 0
+    for k in 1:P
+        H1 = U1[k] + 0.5 * sum(abs2, pm[k])
+        u = rand(m.rng)
+        if isfinite(H1) && log(u) < H0[k] - H1
+            m.particles[k] = progs1[k]; m.logml[k] = lm1[k]; acc += 1
+        end
+    end
+    return acc
+end
+
+const DEFAULT_HMC = (n_leapfrog = 10, eps = 0.02)
+
+"AutoGP.mcmc_parameters!(model, n_hmc) — src/forecasting.jl:65, 148"
+function mcmc_parameters!(m::GPModel, n_hmc::Int; hmc_config = DEFAULT_HMC)
+    t, y = _obs(m)
+    for _ in 1:n_hmc
+        _hmc_move!(m, t, y, hmc_config.n_leapfrog, hmc_config.eps)
+    end
     return m
 end
 
+"AutoGP.mcmc_structure!(model, n_mcmc, n_hmc) — src/forecasting.jl:146"
+function mcmc_structure!(m::GPModel, n_mcmc::Int, n_hmc::Int; hmc_config = DEFAULT_HMC)
+    t, y = _obs(m)
+    for _ in 1:n_mcmc
+        _structure_move!(m, t, y)
+        for _ in 1:n_hmc
+            _hmc_move!(m, t, y, hmc_config.n_leapfrog, hmc_config.eps)
+        end
+    end
+    return m
+end
+
+"AutoGP.maybe_resample!(model, ess) — src/forecasting.jl:138-141 (absolute ESS threshold)"
 function maybe_resample!(m::GPModel, ess_threshold::Real)
     w, ess, _ = weights_normalize(m.log_weights)
     ess < ess_threshold || return false
-    anc = [searchsortedfirst(cumsum(w), rand()) for _ in 1:length(w)]
+    cw = cumsum(w)
+    anc = [min(searchsortedfirst(cw, rand(m.rng)), length(w)) for _ in 1:length(w)]
     m.particles = m.particles[anc]; m.logml = m.logml[anc]; fill!(m.log_weights, 0.0)
     return true
+end
+
+"""
+AutoGP.fit_smc!(model; schedule, n_mcmc, n_hmc, kwargs...) — src/make_and_fit_model.jl:91.
+`n_mcmc` and `n_hmc` have no defaults: omitting them is an UndefKeywordError, as in AutoGP
+(test/test_gpconfig.jl:42).
+"""
+function fit_smc!(m::GPModel; schedule, n_mcmc::Int, n_hmc::Int, hmc_config = DEFAULT_HMC,
+                  biased::Bool = false, shuffle::Bool = true, adaptive_resampling::Bool = true,
+                  adaptive_rejuvenation::Bool = false, verbose::Bool = false)
+    n = length(m.y)
+    m.perm = shuffle ? randperm(m.rng, n) : collect(1:n)
+    P = num_particles(m)
+    for count in schedule
+        count = min(count, n)
+        count <= m.n_obs && continue
+        lm = _refresh_logml(m, count)
+        m.log_weights = _advance(m.log_weights, lm, m.logml)
+        m.logml = lm
+        m.n_obs = count
+        resampled = maybe_resample!(m, adaptive_resampling ? P / 2 : Inf)
+        (!adaptive_rejuvenation || resampled) && mcmc_structure!(m, n_mcmc, n_hmc; hmc_config)
+        verbose && @info "fit_smc!" n_obs = count
+    end
+    return m
+end
+
+"AutoGP.add_data!(model, ds, y) — src/forecasting.jl:135"
+function add_data!(m::GPModel, ds::AbstractVector{<:Dates.TimeType}, y::AbstractVector{<:Real})
+    length(ds) == length(y) || throw(ArgumentError("ds and y must have the same length"))
+    m.n_obs == length(m.y) || error("add_data! on a model that has not absorbed all of its data")
+    n_old = length(m.y)
+    append!(m.ds, ds); append!(m.y, y); append!(m.perm, n_old+1:n_old+length(y))
+    lm = _refresh_logml(m, length(m.y))
+    m.log_weights = _advance(m.log_weights, lm, m.logml)
+    m.logml = lm
+    m.n_obs = length(m.y)
+    return m
 end
 
 struct Mixture
@@ -244,22 +560,76 @@ struct Mixture
     covs::Array{Float64, 3}     # m x m x P
     weights::Vector{Float64}
 end
-function Base.rand(d::Mixture, k::Integer)
+function Base.rand(rng::AbstractRNG, d::Mixture, k::Integer)
     m = size(d.means, 1); out = Matrix{Float64}(undef, m, k); cw = cumsum(d.weights)
     for j in 1:k
-        c = min(searchsortedfirst(cw, rand()), length(cw))
-        out[:, j] = d.means[:, c] + cholesky(Symmetric(d.covs[:, :, c])).L * randn(m)
+        c = min(searchsortedfirst(cw, rand(rng)), length(cw))
+        out[:, j] = d.means[:, c] + cholesky(Symmetric(d.covs[:, :, c])).L * randn(rng, m)
     end
     return out
 end
-Base.rand(d::Mixture) = vec(rand(d, 1))
+Base.rand(d::Mixture, k::Integer) = rand(Random.default_rng(), d, k)     # src/forecasting.jl:47
+Base.rand(d::Mixture) = vec(rand(d, 1))                                  # src/forecasting.jl:67
 
-function predict_mvn(m::GPModel, dates::Vector{Date})
-    mu, sigma, _, info = predict_batch(m.ctx, m.particles, _t(m, m.ds), _yscaled(m, m.y), _t(m, dates))
+"AutoGP.predict_mvn(model, dates) — src/forecasting.jl:46, 66"
+function predict_mvn(m::GPModel, dates::AbstractVector{<:Dates.TimeType})
+    t, y = _obs(m)
+    t_new = m.ds_slope .* _days(dates) .+ m.ds_intercept
+    mu, sigma, _, info = predict_batch(m.ctx, m.particles, t, y, t_new)
     raise_if_not_posdef(info)
-    s = _yslope(m); b = -s * (maximum(m.y) + minimum(m.y)) / 2
     w, _, _ = weights_normalize(m.log_weights)
-    return Mixture((mu .- b) ./ s, sigma ./ s^2, w)
+    return Mixture((mu .- m.y_intercept) ./ m.y_slope, sigma ./ m.y_slope^2, w)
+end
+
+# ---- Dict(model) / GPModel(::Dict): the version-1 wire format of nowcastautogp_amd/wire.py
+#      (src/forecasting.jl:128, 133; the dict is plain data, so deepcopy is a data copy) -------------
+function Base.Dict(m::GPModel)
+    sp = get_spec(m.ctx)
+    cfg = m.config
+    return Dict{String, Any}(
+        "format" => "ngp-model", "version" => 1,
+        "config" => Dict{String, Any}(
+            "node_dist_leaf" => copy(cfg.node_dist_leaf), "node_dist_nocp" => copy(cfg.node_dist_nocp),
+            "node_dist_cp" => copy(cfg.node_dist_cp), "max_branch" => cfg.max_branch,
+            "max_depth" => cfg.max_depth, "changepoints" => cfg.changepoints, "noise" => cfg.noise,
+            "prior" => Dict{String, Any}(String(k) => Dict{String, Any}("mu" => v[:mu], "sigma" => v[:sigma])
+                                         for (k, v) in cfg.prior)),
+        "spec" => Dict{String, Any}("se_form" => sp.se_form, "periodic_form" => sp.periodic_form,
+                                    "cp_form" => sp.cp_form, "jitter" => sp.jitter),
+        "data" => Dict{String, Any}("ds_kind" => "date", "ds" => [string(d) for d in m.ds],
+                                    "y" => copy(m.y)),
+        "transforms" => Dict{String, Any}(
+            "ds" => Dict{String, Any}("slope" => m.ds_slope, "intercept" => m.ds_intercept),
+            "y" => Dict{String, Any}("slope" => m.y_slope, "intercept" => m.y_intercept)),
+        "n_obs" => m.n_obs, "perm" => m.perm .- 1,
+        "n_particles_total" => length(m.particles), "particle_offset" => 0,
+        "particles" => [Dict{String, Any}("ops" => Int.(p.ops), "params" => copy(p.params),
+                                          "noise" => p.noise) for p in m.particles],
+        "log_weights" => copy(m.log_weights), "logml" => copy(m.logml),
+        "depth_cap" => m.depth_cap)
+    # "rng" is optional in the format: Julia's stream is not portable, a reader reseeds
+end
+
+function GPModel(d::AbstractDict; ctx::Context = default_context(),
+                 rng::AbstractRNG = Random.default_rng())
+    d["format"] == "ngp-model" && d["version"] == 1 ||
+        throw(ArgumentError("not a version-1 ngp-model dict"))
+    c = d["config"]
+    prior = Dict{Symbol, Dict{Symbol, Float64}}(
+        Symbol(k) => Dict(:mu => Float64(v["mu"]), :sigma => Float64(v["sigma"])) for (k, v) in c["prior"])
+    cfg = GPConfig(node_dist_leaf = Float64.(c["node_dist_leaf"]),
+                   node_dist_nocp = Float64.(c["node_dist_nocp"]),
+                   node_dist_cp = Float64.(c["node_dist_cp"]), max_branch = c["max_branch"],
+                   max_depth = c["max_depth"], changepoints = c["changepoints"],
+                   noise = c["noise"] === nothing ? nothing : Float64(c["noise"]), prior = prior)
+    d["data"]["ds_kind"] == "date" || throw(ArgumentError("this reader needs date-valued ds"))
+    parts = [Program(Int32.(p["ops"]), Float64.(p["params"]), Float64(p["noise"]))
+             for p in d["particles"]]
+    tr = d["transforms"]
+    return GPModel(cfg, Date.(d["data"]["ds"]), Float64.(d["data"]["y"]), parts,
+                   Float64.(d["log_weights"]), Float64.(d["logml"]), d["n_obs"],
+                   Int.(d["perm"]) .+ 1, tr["ds"]["slope"], tr["ds"]["intercept"],
+                   tr["y"]["slope"], tr["y"]["intercept"], d["depth_cap"], rng, ctx)
 end
 
 end # module

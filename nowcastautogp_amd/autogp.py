@@ -295,42 +295,20 @@ class GPModel:
 
     # -- Dict(model) / GPModel(dict)  (reference src/forecasting.jl:128,133) ----------------------
     def to_dict(self) -> dict:
-        return {
-            "config": self.config,   # kept by identity, like the reference's model.config === cfg
-            "ds": list(self.ds), "y": self.y.copy(), "days": self.days.copy(),
-            "ds_transform": (self.ds_transform.slope, self.ds_transform.intercept),
-            "y_transform": (self.y_transform.slope, self.y_transform.intercept),
-            "depth_cap": self.depth_cap, "n_particles_total": self.n_particles_total,
-            "particles": [dict(ops=p.program()[0].tolist(), params=p.program()[1].tolist(),
-                               noise=p.noise) for p in self.particles],
-            "log_weights": self.log_weights.copy(), "n_obs": self.n_obs,
-            "perm": self._perm.copy(), "logml": self._logml.copy(),
-            "rng_root": self._root, "rng_generation": self._gen,
-            "rng_particle_states": [copy.deepcopy(r.bit_generator.state) for r in self.prng],
-            "rng_shared_state": copy.deepcopy(self.rng_shared.bit_generator.state),
-        }
+        """The versioned, JSON-serialisable snapshot of ``nowcastautogp_amd.wire`` (plain data: a
+        ``deepcopy`` is a data copy, ``json.dumps`` works, no live objects)."""
+        from . import wire
+        spec = None
+        eng = self.engine
+        if eng is not None and hasattr(eng, "ctx"):
+            sp = eng.ctx.get_spec()
+            spec = dict(se_form=sp.se_form, periodic_form=sp.periodic_form, cp_form=sp.cp_form,
+                        jitter=sp.jitter)
+        return wire.model_to_wire(self, spec)
 
     def _load(self, d: dict):
-        self.config = d["config"]
-        self.ds, self.y, self.days = list(d["ds"]), np.array(d["y"], float), np.array(d["days"], float)
-        self.ds_transform = LinearTransform(*d["ds_transform"])
-        self.y_transform = LinearTransform(*d["y_transform"])
-        self.depth_cap = d["depth_cap"]
-        self.n_particles_total = d["n_particles_total"]
-        self.particles = [Particle(gp.from_program(p["ops"], p["params"]), float(p["noise"]))
-                          for p in d["particles"]]
-        self.log_weights = np.array(d["log_weights"], float)
-        self.n_obs = int(d["n_obs"])
-        self._perm = np.array(d["perm"])
-        self._logml = np.array(d["logml"], float)
-        self._root, self._gen = int(d["rng_root"]), int(d["rng_generation"])
-        self.prng = []
-        for st in d["rng_particle_states"]:
-            r = np.random.Generator(np.random.PCG64())
-            r.bit_generator.state = copy.deepcopy(st)
-            self.prng.append(r)
-        self.rng_shared = np.random.Generator(np.random.PCG64())
-        self.rng_shared.bit_generator.state = copy.deepcopy(d["rng_shared_state"])
+        from . import wire
+        wire.model_from_wire(self, d)
 
     def reseed(self, root: int) -> None:
         """Fresh streams for a clone (forecast_with_nowcasts gives every scenario its own root)."""

@@ -125,5 +125,29 @@ def main():
     print(f"{len(cases)} cases, worst C-vs-numpy disagreement / tolerance = {worst:.2f} -> {out}")
 
 
+def make_model_dict():
+    """tests/golden/model_dict_v1.json: a fitted two-particle model in the version-1 wire format
+    (nowcastautogp_amd/wire.py) with the predictive mixture it must reproduce.  The fit runs on the
+    CPU oracle engine (tests/engine_oracle.py): a data fixture of THIS repository, not a reference
+    output (the reference holds none)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from nowcastautogp_amd import autogp
+    from tests import mirror_contracts as mc
+    from tests.engine_oracle import OracleEngine
+    model = mc.fitted(OracleEngine(), seed=31, n_particles=2, n_mcmc=3, n_hmc=2)
+    mix = autogp.predict_mvn(model, mc.days(20, 23))
+    out = {"what": "GPModel.to_dict() of a fitted model + predict_mvn on 3 dates after the data",
+           "model": model.to_dict(),
+           "predict": {"means": mix.means.tolist(), "covs": mix.covs.tolist(),
+                       "weights": mix.weights.tolist()}}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "model_dict_v1.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
-    main()
+    if "--model-dict" in sys.argv:      # python tests/golden/make_golden.py --model-dict
+        make_model_dict()
+    else:
+        main()

@@ -134,7 +134,7 @@ def check_forecast_with_nowcasts(engine):
     assert nc.forecast_with_nowcasts(base, multi, days(12, 16), 3).shape == (4, 6)   # :222
     # the base model is never mutated (src/forecasting.jl:101)
     after = base.to_dict()
-    assert after["n_obs"] == before["n_obs"] and np.array_equal(after["y"], before["y"])
+    assert after["n_obs"] == before["n_obs"] and after["data"] == before["data"]
     assert after["particles"] == before["particles"]
     # assertion errors (:227-235)
     with pytest.raises(AssertionError):
@@ -180,3 +180,11 @@ def check_snapshot_round_trip(engine):
     b = autogp.predict_mvn(clone, days(20, 23))
     assert np.array_equal(a.means, b.means) and np.array_equal(a.covs, b.covs)
     assert np.array_equal(a.rand(4), b.rand(4))     # rng state travels with the snapshot
+    # the snapshot is the versioned wire format: pure JSON data, survives a JSON round trip
+    import json
+    from nowcastautogp_amd import wire
+    wire.validate(d)
+    again = nc.GPModel(json.loads(json.dumps(model.to_dict())), engine=engine)
+    assert again.to_dict() == model.to_dict()
+    c = autogp.predict_mvn(again, days(20, 23))
+    assert np.array_equal(a.means, c.means) and np.array_equal(a.covs, c.covs)
