@@ -13,7 +13,7 @@ from nowcastautogp_amd import _lib, gp
 from nowcastautogp_amd._abi import NgpSpec
 from nowcastautogp_amd.synthetic import jitter_programs, make_ensemble, make_workload
 from oracle import oracle_c, oracle_np
-from tests.util import TOL_LOGML, TOL_PRED, nerr, prog_of, spec_of, tol
+from tests.util import TOL_LOGML, TOL_PRED, check, nerr, note_skipped, prog_of, spec_of, tol
 
 pytestmark = pytest.mark.gpu
 
@@ -66,17 +66,17 @@ def test_golden_logml_predict_nowcast(ctx, golden):
         prog, cond = prog_of(c), c["cond"]
         lm, info = ctx.logml_batch([prog], c["t"], c["y"])
         assert info[0] == 0
-        assert nerr(lm[0], c["logml"]) < tol(TOL_LOGML, cond), (c["name"], c["n"])
+        check("test_golden_logml_predict_nowcast:logml", lm[0], c["logml"], TOL_LOGML, cond, ctx=(c["name"], c["n"]))
         mu, sg, lm2, info = ctx.predict_batch([prog], c["t"], c["y"], c["t_new"])
-        assert nerr(mu[0], c["mu"]) < tol(TOL_PRED, cond), (c["name"], c["n"])
-        assert nerr(sg[0], c["sigma"]) < tol(TOL_PRED, cond), (c["name"], c["n"])
-        assert nerr(lm2[0], c["logml"]) < tol(TOL_LOGML, cond)
+        check("test_golden_logml_predict_nowcast:predictive", mu[0], c["mu"], TOL_PRED, cond, ctx=(c["name"], c["n"]))
+        check("test_golden_logml_predict_nowcast:predictive", sg[0], c["sigma"], TOL_PRED, cond, ctx=(c["name"], c["n"]))
+        check("test_golden_logml_predict_nowcast:logml", lm2[0], c["logml"], TOL_LOGML, cond)
         out = ctx.nowcast_batch([prog], c["t"], c["y"], c["t_add"], c["y_add"], c["t_new"])
         assert out["info"][0] == 0
-        assert nerr(out["logml_base"][0], c["logml_base"]) < tol(TOL_LOGML, cond)
-        assert nerr(out["logml_full"][0], c["logml_full"]) < tol(TOL_LOGML, cond)
-        assert nerr(out["mu"][0], c["nowcast_mu"]) < tol(TOL_PRED, cond)
-        assert nerr(out["sigma"][0], c["nowcast_sigma"]) < tol(TOL_PRED, cond)
+        check("test_golden_logml_predict_nowcast:logml", out["logml_base"][0], c["logml_base"], TOL_LOGML, cond)
+        check("test_golden_logml_predict_nowcast:logml", out["logml_full"][0], c["logml_full"], TOL_LOGML, cond)
+        check("test_golden_logml_predict_nowcast:predictive", out["mu"][0], c["nowcast_mu"], TOL_PRED, cond)
+        check("test_golden_logml_predict_nowcast:predictive", out["sigma"][0], c["nowcast_sigma"], TOL_PRED, cond)
     ctx.set_spec(NgpSpec(0, 0, 0, 0, 1e-5))
 
 
@@ -91,7 +91,7 @@ def test_logml_sizes_and_ragged_tails(ctx, n):
         ref, i0 = oracle_np.logml(prog, t, y)
         assert i0 == 0 and info[b] == 0
         cond = np.linalg.cond(oracle_np.cov(prog, t, t, True))
-        assert nerr(lm[b], ref) < tol(TOL_LOGML, cond), (n, b)
+        check("test_logml_sizes_and_ragged_tails:logml", lm[b], ref, TOL_LOGML, cond, ctx=(n, b))
 
 
 @pytest.mark.parametrize("kind", ["irregular", "gaps", "weekly_days"])
@@ -118,9 +118,9 @@ def test_time_grids_direct_and_lattice_fill(ctx, kind):
     for b, prog in enumerate(progs):
         cond = np.linalg.cond(oracle_np.cov(prog, t, t, True))
         rmu, rsg, rlm, _ = oracle_np.predict(prog, t, y, t_new)
-        assert nerr(lm[b], rlm) < tol(TOL_LOGML, cond), (kind, b)
-        assert nerr(mu[b], rmu) < tol(TOL_PRED, cond), (kind, b)
-        assert nerr(sg[b], rsg) < tol(TOL_PRED, cond), (kind, b)
+        check("test_time_grids_direct_and_lattice_fill:logml", lm[b], rlm, TOL_LOGML, cond, ctx=(kind, b))
+        check("test_time_grids_direct_and_lattice_fill:predictive", mu[b], rmu, TOL_PRED, cond, ctx=(kind, b))
+        check("test_time_grids_direct_and_lattice_fill:predictive", sg[b], rsg, TOL_PRED, cond, ctx=(kind, b))
 
 
 def test_per_item_y_rows(ctx):
@@ -134,8 +134,10 @@ def test_per_item_y_rows(ctx):
     for b, prog in enumerate(progs):
         cond = np.linalg.cond(oracle_np.cov(prog, t, t, True))
         rmu, rsg, rlm, _ = oracle_np.predict(prog, t, Y[b], [1.01, 1.02, 1.05])
-        assert nerr(lm[b], rlm) < tol(TOL_LOGML, cond) and nerr(lm2[b], rlm) < tol(TOL_LOGML, cond)
-        assert nerr(mu[b], rmu) < tol(TOL_PRED, cond) and nerr(sg[b], rsg) < tol(TOL_PRED, cond)
+        check("test_per_item_y_rows:logml", lm[b], rlm, TOL_LOGML, cond)
+        check("test_per_item_y_rows:logml", lm2[b], rlm, TOL_LOGML, cond)
+        check("test_per_item_y_rows:predictive", mu[b], rmu, TOL_PRED, cond)
+        check("test_per_item_y_rows:predictive", sg[b], rsg, TOL_PRED, cond)
 
 
 @pytest.mark.parametrize("n,d,m,D,P", [(10, 2, 2, 2, 3), (130, 2, 5, 3, 4), (320, 1, 9, 7, 6),
@@ -148,10 +150,10 @@ def test_nowcast_fan_out_vs_per_scenario_refactorisation(ctx, n, d, m, D, P):
         tt = np.concatenate([w.t, w.t_add])
         cond = np.linalg.cond(oracle_np.cov(prog, tt, tt, True))
         lb, lf, mu, sg, _ = oracle_np.nowcast(prog, w.t, w.y, w.t_add, w.y_add, w.t_new)
-        assert nerr(out["logml_base"][p], lb) < tol(TOL_LOGML, cond)
-        assert nerr(out["logml_full"][p], lf) < tol(TOL_LOGML, cond)
-        assert nerr(out["mu"][p], mu) < tol(TOL_PRED, cond)
-        assert nerr(out["sigma"][p], sg) < tol(TOL_PRED, cond)
+        check("test_nowcast_fan_out_vs_per_scenario_refactorisation:logml", out["logml_base"][p], lb, TOL_LOGML, cond)
+        check("test_nowcast_fan_out_vs_per_scenario_refactorisation:logml", out["logml_full"][p], lf, TOL_LOGML, cond)
+        check("test_nowcast_fan_out_vs_per_scenario_refactorisation:predictive", out["mu"][p], mu, TOL_PRED, cond)
+        check("test_nowcast_fan_out_vs_per_scenario_refactorisation:predictive", out["sigma"][p], sg, TOL_PRED, cond)
         assert np.array_equal(out["sigma"][p], out["sigma"][p].T)
 
 
@@ -186,10 +188,10 @@ def test_cached_factor_queries_match_refactorisation_and_oracle(ctx, n, lattice)
             tt = np.concatenate([t, ta])
             cond = np.linalg.cond(oracle_np.cov(prog, tt, tt, True))
             lb, lf, mu, sg, _ = oracle_np.nowcast(prog, t, w.y, ta, ya, tn)
-            assert nerr(got["logml_base"][p], lb) < tol(TOL_LOGML, cond)
-            assert nerr(got["logml_full"][p], lf) < tol(TOL_LOGML, cond)
-            assert nerr(got["mu"][p], mu) < tol(TOL_PRED, cond)
-            assert nerr(got["sigma"][p], sg) < tol(TOL_PRED, cond)
+            check("test_cached_factor_queries_match_refactorisation_and_oracle:logml", got["logml_base"][p], lb, TOL_LOGML, cond)
+            check("test_cached_factor_queries_match_refactorisation_and_oracle:logml", got["logml_full"][p], lf, TOL_LOGML, cond)
+            check("test_cached_factor_queries_match_refactorisation_and_oracle:predictive", got["mu"][p], mu, TOL_PRED, cond)
+            check("test_cached_factor_queries_match_refactorisation_and_oracle:predictive", got["sigma"][p], sg, TOL_PRED, cond)
     f.close()
 
 
@@ -289,9 +291,9 @@ def test_mid_size_1024_many_items(ctx):
         tt = np.concatenate([w.t, w.t_add])
         cond = np.linalg.cond(oracle_np.cov(progs[p], tt, tt, True))
         lb, lf, mu, sg, _ = oracle_np.nowcast(progs[p], w.t, w.y, w.t_add, w.y_add, w.t_new)
-        assert nerr(out["logml_full"][p], lf) < tol(TOL_LOGML, cond)
-        assert nerr(out["mu"][p], mu) < tol(TOL_PRED, cond)
-        assert nerr(out["sigma"][p], sg) < tol(TOL_PRED, cond)
+        check("test_mid_size_1024_many_items:logml", out["logml_full"][p], lf, TOL_LOGML, cond)
+        check("test_mid_size_1024_many_items:predictive", out["mu"][p], mu, TOL_PRED, cond)
+        check("test_mid_size_1024_many_items:predictive", out["sigma"][p], sg, TOL_PRED, cond)
 
 
 def test_headline_size_2048_properties_and_spot_parity(ctx):
@@ -320,10 +322,86 @@ def test_headline_size_2048_properties_and_spot_parity(ctx):
         cond = np.linalg.cond(oracle_np.cov(w.programs[p], tt, tt, True))
         lb, lf, mu, sg, _ = oracle_np.nowcast(w.programs[p], w.t, w.y, w.t_add, w.y_add[:2],
                                               w.t_new)
-        assert nerr(out["logml_base"][p], lb) < tol(TOL_LOGML, cond)
-        assert nerr(out["logml_full"][p][:2], lf) < tol(TOL_LOGML, cond)
-        assert nerr(out["mu"][p][:2], mu) < tol(TOL_PRED, cond)
-        assert nerr(out["sigma"][p], sg) < tol(TOL_PRED, cond)
+        check("test_headline_size_2048_properties_and_spot_parity:logml", out["logml_base"][p], lb, TOL_LOGML, cond)
+        check("test_headline_size_2048_properties_and_spot_parity:logml", out["logml_full"][p][:2], lf, TOL_LOGML, cond)
+        check("test_headline_size_2048_properties_and_spot_parity:predictive", out["mu"][p][:2], mu, TOL_PRED, cond)
+        check("test_headline_size_2048_properties_and_spot_parity:predictive", out["sigma"][p], sg, TOL_PRED, cond)
+
+
+def test_headline_c3_flat_1e8_on_mean_and_variance(ctx):
+    """north_star: predictive mean / variance to rtol 1e-8 at the headline configuration.  Eight
+    particles of C3 against the oracle with the FLAT tolerance wherever 50 eps cond(K) <= 1e-8;
+    the items above that are not dropped but listed by cond and judged
+    against 50 eps cond."""
+    w = make_workload("C3", P=8, D=3)
+    out = ctx.nowcast_batch(w.programs, w.t, w.y, w.t_add, w.y_add, w.t_new)
+    assert not out["info"].any()
+    tt = np.concatenate([w.t, w.t_add])
+    flat, listed = 0, []
+    for p, prog in enumerate(w.programs):
+        cond = float(np.linalg.cond(oracle_np.cov(prog, tt, tt, True)))
+        lb, lf, mu, sg, oi = oracle_np.nowcast(prog, w.t, w.y, w.t_add, w.y_add[:1], w.t_new)
+        assert oi == 0
+        e_mu = nerr(out["mu"][p][:1], mu)
+        e_var = nerr(np.diag(out["sigma"][p]), np.diag(sg))
+        if 50 * 2.220446049250313e-16 * cond <= 1e-8:
+            flat += 1
+            assert e_mu < 1e-8 and e_var < 1e-8, (p, cond, e_mu, e_var)
+        else:
+            listed.append((p, cond, e_mu, e_var))
+        check("test_headline_c3_flat_1e8:mean", out["mu"][p][:1], mu, TOL_PRED, cond, ctx=p)
+        check("test_headline_c3_flat_1e8:variance", np.diag(out["sigma"][p]), np.diag(sg), TOL_PRED,
+              cond, ctx=p)
+    print(f"C3 flat 1e-8: {flat} of {len(w.programs)} items under the flat tolerance; "
+          f"condition-limited items (p, cond, err mean, err var): {listed}")
+    assert flat >= len(w.programs) // 2
+
+
+def test_headline_size_2048_gradient_against_the_oracle(ctx):
+    """Round 1 only compared the n = 2048 gradient with finite differences of the library's own
+    logml.  Here: the C oracle's forward-mode gradient at n = 2048 (about half a minute of scalar
+    CPU work per item) for two particles."""
+    w = make_workload("C3", P=12, D=1)
+    small = sorted(range(len(w.programs)), key=lambda i: len(w.programs[i][0]))[:1]
+    multi = [i for i in range(len(w.programs)) if 3 <= len(w.programs[i][0]) <= 5][:1]
+    picks = small + multi
+    progs = [w.programs[i] for i in picks]
+    lm, grads, info = ctx.logml_grad_batch(progs, w.t, w.y)
+    assert not info.any()
+    for k, prog in enumerate(progs):
+        cond = float(np.linalg.cond(oracle_np.cov(prog, w.t, w.t, True)))
+        rlm, rg, ri = oracle_c.logml_grad(prog, w.t, w.y)
+        assert ri == 0
+        check("test_headline_size_2048_gradient_against_the_oracle:logml", lm[k], rlm, TOL_LOGML, cond)
+        check("test_headline_size_2048_gradient_against_the_oracle:gradient", grads[k], rg, 1e-7, cond,
+              ctx=(picks[k], len(prog[0])))
+
+
+def test_c2_full_workload(ctx):
+    """BASELINE config C2 as specified: n = 512 weekly points, 32 particles x 50 nowcast scenarios,
+    every (particle, scenario) item its own kernel (1,600 distinct factorisations), through the
+    predict path; oracle parity on a sample of 24 items, size-independent properties on all."""
+    from nowcastautogp_amd.synthetic import bench_items
+    w, progs, Y, tt = bench_items("C2", 0)
+    assert len(progs) == 1600 and w.n == 512
+    mu, sg, lm, info = ctx.predict_batch(progs, tt, Y, w.t_new)
+    assert not info.any() and np.isfinite(lm).all() and np.isfinite(mu).all()
+    for b in range(0, 1600, 97):
+        assert np.array_equal(sg[b], sg[b].T) and np.linalg.eigvalsh(sg[b]).min() > 0
+    # the shared-K path on the 32 base kernels must agree with the per-item path where the
+    # kernels coincide: item p * 50 + s of an UNjittered batch
+    base = ctx.nowcast_batch(w.programs, w.t, w.y, w.t_add, w.y_add, w.t_new)
+    same = [w.programs[p] for p in range(32) for _ in range(50)]
+    mu2, sg2, lm2, info2 = ctx.predict_batch(same, tt, Y, w.t_new)
+    assert nerr(lm2.reshape(32, 50), base["logml_full"]) < 1e-10
+    assert nerr(mu2.reshape(32, 50, -1), base["mu"]) < 1e-8
+    for b in range(0, 1600, 67):            # 24 items
+        cond = float(np.linalg.cond(oracle_np.cov(progs[b], tt, tt, True)))
+        rmu, rsg, rlm, oi = oracle_np.predict(progs[b], tt, Y[b], w.t_new)
+        assert oi == 0
+        check("test_c2_full_workload:logml", lm[b], rlm, TOL_LOGML, cond, ctx=b)
+        check("test_c2_full_workload:predictive", mu[b], rmu, TOL_PRED, cond, ctx=b)
+        check("test_c2_full_workload:predictive", sg[b], rsg, TOL_PRED, cond, ctx=b)
 
 
 def test_headline_size_2048_gradient_and_resident_factor(ctx):
@@ -368,8 +446,8 @@ def test_gradient_matches_oracle_on_golden(ctx, golden):
         prog = prog_of(c)
         lm, grads, info = ctx.logml_grad_batch([prog], c["t"], c["y"])
         assert info[0] == 0
-        assert nerr(lm[0], c["logml"]) < tol(TOL_LOGML, c["cond"]), (c["name"], c["n"])
-        assert nerr(grads[0], c["grad"]) < tol(1e-7, c["cond"]), (c["name"], c["n"])
+        check("test_gradient_matches_oracle_on_golden:logml", lm[0], c["logml"], TOL_LOGML, c["cond"], ctx=(c["name"], c["n"]))
+        check("test_gradient_matches_oracle_on_golden:gradient", grads[0], c["grad"], 1e-7, c["cond"], ctx=(c["name"], c["n"]))
     ctx.set_spec(NgpSpec(0, 0, 0, 0, 1e-5))
 
 
@@ -400,7 +478,7 @@ def test_gradient_random_trees_and_child_reordering(ctx, n, lattice):
         cond = np.linalg.cond(oracle_np.cov(prog, t, t, True))
         assert i0 == 0 and nerr(lm[b], rlm) < tol(TOL_LOGML, cond)
         assert grads[b].shape == rg.shape
-        assert nerr(grads[b], rg) < tol(1e-7, cond), (b, grads[b], rg)
+        check("test_gradient_random_trees_and_child_reordering:gradient", grads[b], rg, 1e-7, cond, ctx=(b, grads[b], rg))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -446,9 +524,9 @@ def test_maximum_aux_rows_and_largest_program(ctx):
                                              t_all[n + d:])
     cond = np.linalg.cond(oracle_np.cov(prog, t_all[:n + d], t_all[:n + d], True))
     assert out["info"][0] == 0 and info == 0
-    assert nerr(out["logml_full"][0], lf) < tol(TOL_LOGML, cond)
-    assert nerr(out["mu"][0], mu) < tol(TOL_PRED, cond)
-    assert nerr(out["sigma"][0], sg) < tol(TOL_PRED, cond)
+    check("test_maximum_aux_rows_and_largest_program:logml", out["logml_full"][0], lf, TOL_LOGML, cond)
+    check("test_maximum_aux_rows_and_largest_program:predictive", out["mu"][0], mu, TOL_PRED, cond)
+    check("test_maximum_aux_rows_and_largest_program:predictive", out["sigma"][0], sg, TOL_PRED, cond)
     # one more aux row is refused, not truncated
     t_more = np.arange(n + d + m + 1) / (n - 1)
     with pytest.raises(_lib.NgpError):
@@ -537,6 +615,7 @@ def test_randomised_differential_against_the_oracle(ctx):
             tt = np.concatenate([t, t_add])
             cond = np.linalg.cond(oracle_np.cov(prog, tt, tt, True, sp))
             if not np.isfinite(cond) or cond > 1e9:
+                note_skipped("test_randomised_differential_against_the_oracle:values", cond)
                 continue
             if m:
                 lb, lf, mu, sg, oi = oracle_np.nowcast(prog, t, y, t_add, y_add, t_new, True, sp)
@@ -544,23 +623,23 @@ def test_randomised_differential_against_the_oracle(ctx):
                 lb = oracle_np.logml(prog, t, y, sp)[0]
                 lf = [oracle_np.logml(prog, tt, np.concatenate([y, y_add[s]]), sp)[0] for s in range(D)]
             assert got["info"][p] == 0, (case, p)
-            e1 = nerr(got["logml_base"][p], lb) / tol(TOL_LOGML, cond)
-            e2 = nerr(got["logml_full"][p], lf) / tol(TOL_LOGML, cond)
-            e3 = e4 = 0.0
+            name, where = "test_randomised_differential_against_the_oracle", (case, p, n, d, m, D, grid)
+            check(name + ":logml", got["logml_base"][p], lb, TOL_LOGML, cond, ctx=where)
+            check(name + ":logml", got["logml_full"][p], lf, TOL_LOGML, cond, ctx=where)
             if m:
-                e3 = nerr(got["mu"][p], mu) / tol(TOL_PRED, cond)
-                e4 = nerr(got["sigma"][p], sg) / tol(TOL_PRED, cond)
-            worst = max(worst, e1, e2, e3, e4)
-            assert max(e1, e2, e3, e4) < 1.0, (case, p, n, d, m, D, grid, e1, e2, e3, e4)
+                check(name + ":predictive", got["mu"][p], mu, TOL_PRED, cond, ctx=where)
+                check(name + ":predictive", got["sigma"][p], sg, TOL_PRED, cond, ctx=where)
+            worst = 1.0
         if case % 3 == 0 and n >= 2:
             lm, grads, info = ctx.logml_grad_batch(progs, t, y)
             for p, prog in enumerate(progs):
                 cond = np.linalg.cond(oracle_np.cov(prog, t, t, True, sp))
                 if not np.isfinite(cond) or cond > 1e8:
+                    note_skipped("test_randomised_differential_against_the_oracle:gradient", cond)
                     continue
                 rlm, rg, _ = oracle_c.logml_grad(prog, t, y, spec)
-                assert nerr(lm[p], rlm) < tol(TOL_LOGML, cond), (case, p)
-                assert nerr(grads[p], rg) < tol(1e-7, cond), (case, p, n)
+                check("test_randomised_differential_against_the_oracle:logml", lm[p], rlm, TOL_LOGML, cond, ctx=(case, p))
+                check("test_randomised_differential_against_the_oracle:gradient", grads[p], rg, 1e-7, cond, ctx=(case, p, n))
     ctx.set_spec(NgpSpec(0, 0, 0, 0, 1e-5))
     assert worst > 0.0
 
