@@ -468,8 +468,13 @@ inline Lane lane_of(ngp_ctx *c) { return Lane{c->stream, c->side, c->ev_fork, c-
 // dinv_step != 0: block column jj writes / reads its M at p.dinv + jj * dinv_step (cached factor:
 // every M_j is kept); 0: one buffer reused by every step.
 // sp != null and p0.L32 set: mixed-precision job (fat steps on chol_col_glds_kernel<MIXED>, class 9).
-void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p0, int bc, EventTimer &tm,
-                  size_t dinv_step = 0, const DevSpec *sp = nullptr) {
+// order_buf / order_prev ([bc] each, mixed jobs): every MIXED_REORDER block columns the items are
+// re-ranked by the fp64 tile products they needed since the last ranking.
+constexpr int MIXED_REORDER = 16;
+void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int bc, EventTimer &tm,
+                  size_t dinv_step = 0, const DevSpec *sp = nullptr, int32_t *order_buf = nullptr,
+                  unsigned *order_prev = nullptr) {
+    ChunkPtrs p0 = p_in;
     const bool mixed = sp != nullptr && p0.L32 != nullptr;
     hipStream_t s = ln.main;
     const double nrows_aux = (double)g.naux;
@@ -508,6 +513,10 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p0, int bc,
         // class 6: the direct-load kernel of the thin / full steps
         tm.run(fat ? (mixed ? 9 : 0) : 6, bc * fl, bc * by,
                [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, s, sp); });
+        if (mixed && fat && order_buf && jj >= 8 && jj % MIXED_REORDER == 8) {
+            launch_mixed_order(p0, order_prev, order_buf, bc, s);
+            p0.order = order_buf;
+        }
         if (ahead && jj > 0) {
             (void)hipEventRecord(ln.fork, s);
             (void)hipStreamWaitEvent(ln.side, ln.fork, 0);
@@ -779,7 +788,7 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
         return st;
     };
     void *Lbuf = nullptr, *dinv = nullptr, *tab = nullptr, *sig = nullptr;
-    void *L32 = nullptr, *tmx = nullptr, *cnt = nullptr;
+    void *L32 = nullptr, *tmx = nullptr, *cnt = nullptr, *order_buf = nullptr, *order_prev = nullptr;
     RefineBufs rb;
     bool single_chunk = false;
     if (g.n0 > 0) {
@@ -804,6 +813,8 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
             st = dalloc(&L32, (l_bytes / 2) * (size_t)Bc);
             if (!st) st = dalloc(&tmx, 4 * nbt * g.nb0 * (size_t)Bc);
             if (!st) st = dalloc(&cnt, 8 * (size_t)Bc);
+            if (!st) st = dalloc(&order_buf, 4 * (size_t)Bc);
+            if (!st) st = dalloc(&order_prev, 4 * (size_t)Bc);
             if (!st) st = dalloc((void **)&rb.X, aux_bytes * (size_t)Bc);
         }
         if (!st && refine) {
@@ -844,7 +855,9 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
             const double fill_elems =
                 (double)bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0);
             tm.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, s); });
-            factor_chunk(ln, g, p, bc, tm, mstep, mixed ? &sp : nullptr);
+            if (mixed) HIPCHK(hipMemsetAsync(order_prev, 0, 4 * (size_t)bc, s));
+            factor_chunk(ln, g, p, bc, tm, mstep, mixed ? &sp : nullptr, (int32_t *)order_buf,
+                         (unsigned *)order_prev);
             double *Gchunk = j->G + (int64_t)b0 * g.naux * g.naux;
             tm.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0,
                    [&] { launch_gram(g, (const double *)Lbuf, Gchunk, bc, s); });

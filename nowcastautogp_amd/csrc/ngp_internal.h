@@ -97,6 +97,7 @@ struct ChunkPtrs {
                           // (row tile, block column); aux tiles follow the nb0 main row tiles
     unsigned     *mixcnt; // [Bc][2] tile products of the fat steps that ran in fp32 / in fp64
     double       *auxX;   // [Bc][naux_pad][n0] the fill also leaves the aux rows X here
+    const int32_t *order; // mixed fat steps: dispatch order of the items (heaviest first) or null
     const int32_t *items; // refinement sweeps: the items (indices into the chunk) a launch works
                           // on, Bc = their count; null: all of them in order
 };
@@ -144,6 +145,8 @@ void launch_refine_gram(const JobGeom &g, const double *A, const double *X, cons
                         const int32_t *items, hipStream_t s);
 void launch_mfma_f32_probe(const float *A, const float *Bm, float *Dout, hipStream_t s);
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
+// order <- items by fp64 tile products since the last call, most first (prev: [Bc] snapshot)
+void launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int Bc, hipStream_t s);
 void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
                       int Bc, hipStream_t s);

@@ -1153,9 +1153,12 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 
     const int wg = blockIdx.x;
     const int xcd = wg & 7, idx = wg >> 3;       // blocks b and b+8 share an XCD (speed only)
-    const int item = (idx / st.groups) * 8 + xcd;
+    const int slot = (idx / st.groups) * 8 + xcd;
     const int grp = idx % st.groups;
-    if (item >= Bc) return;                      // whole workgroup, before any barrier
+    if (slot >= Bc) return;                      // whole workgroup, before any barrier
+    // mixed-precision batches: items with the most fp64 tile products are dispatched first
+    // (mixed_order_kernel), so that a launch does not end on its slowest workgroups
+    const int item = (MIXED && p.order) ? p.order[slot] : slot;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ltile = wave >> 1, col = wave & 1;
@@ -1481,6 +1484,25 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     } else {
         solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
                             reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES));
+    }
+}
+
+// order[slot] = the item with the slot-th largest number of fp64 tile products since the previous
+// call (mixcnt[2 i + 1] counts them; prev keeps the snapshot), ties by index.  One workgroup.
+__global__ __launch_bounds__(256) void mixed_order_kernel(const unsigned *mixcnt, unsigned *prev,
+                                                          int32_t *order, int Bc) {
+    extern __shared__ unsigned keys[];
+    for (int i = threadIdx.x; i < Bc; i += 256) {
+        const unsigned now = mixcnt[2 * i + 1];
+        keys[i] = now - prev[i];
+        prev[i] = now;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Bc; i += 256) {
+        const unsigned k = keys[i];
+        int rank = 0;
+        for (int o = 0; o < Bc; ++o) rank += (keys[o] > k) || (keys[o] == k && o < i);
+        order[rank] = i;
     }
 }
 
@@ -2769,6 +2791,11 @@ void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipS
     const int n = (g.naux_pad / NB) * (g.nb0 - 1 - j);
     if (n <= 0) return;
     hipLaunchKernelGGL(aux_update_kernel, dim3((n + 3) / 4, Bc), dim3(256), 0, s, g, p, j);
+}
+
+void launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int Bc, hipStream_t s) {
+    hipLaunchKernelGGL(mixed_order_kernel, dim3(1), dim3(256), sizeof(unsigned) * (size_t)Bc, s,
+                       (const unsigned *)p.mixcnt, prev, order, Bc);
 }
 
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {
