@@ -75,12 +75,13 @@ def cpu_baseline(config, rank, args, idx, gpu_logml):
     """oracle/cpu_baseline.py in a child process: the numpy / LAPACK oracle, one worker PROCESS
     per core with one BLAS thread each (how the reference runs: src/forecasting.jl:2-10, 131-132)
     on a bounded sample of the same items."""
-    cores = os.cpu_count() or 1
-    # a worker holds K, its factor and temporaries: ~3 n^2 doubles
+    # a worker holds K, its factor and temporaries: ~3 n^2 doubles; the child takes every core it
+    # may run on (affinity mask, cgroup quota) up to that memory cap
     n = args.n or {"C5": 8192}.get(config, 2048)
-    workers = max(1, min(cores, int(200e9 / (3 * 8 * (n + 16) ** 2 * 1.5))))
+    cap = max(1, int(200e9 / (3 * 8 * (n + 16) ** 2 * 1.5)))
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--config", config,
-           "--rank", str(rank), "--items", ",".join(str(i) for i in idx), "--workers", str(workers)]
+           "--rank", str(rank), "--items", ",".join(str(i) for i in idx), "--workers", "0",
+           "--max-workers", str(cap)]
     for flag, v in (("--n", args.n), ("--particles", args.particles), ("--scenarios", args.scenarios)):
         if v is not None:
             cmd += [flag, str(v)]
@@ -95,7 +96,9 @@ def cpu_baseline(config, rank, args, idx, gpu_logml):
             "kind": "port",
             "sample": f"{len(idx)} of the items (numpy/scipy OpenBLAS oracle: covariance assembly + "
                       f"dpotrf + solves), {r['workers']} worker processes x 1 BLAS thread on "
-                      f"{cores} host cores, {r['wall_s']:.1f} s wall ({time.perf_counter() - t0:.1f} s "
+                      f"{r['usable_cores']} usable of {r['host_cores']} host cores"
+                      + (f" (cgroup quota {r['cgroup_cpu_quota']:g})" if r.get("cgroup_cpu_quota") else "")
+                      + f", {r['wall_s']:.1f} s wall ({time.perf_counter() - t0:.1f} s "
                       "with start-up)",
             "per_core": {"items_per_s_one_core_alone": r.get("one_core_items_per_s"),
                          "items_per_s_per_core_all_busy": r["items_per_s"] / r["workers"],
@@ -171,11 +174,12 @@ def fit_forecast_wallclock(w, device, rank, args):
     sizes = sorted({k[1] for k in eng.trace})
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--config", args.config,
            "--rank", str(rank), "--sizes", ",".join(str(s) for s in sizes), "--per-size", "2",
-           "--workers", str(min(os.cpu_count() or 1, 2 * len(sizes)))]
+           "--workers", "0", "--max-workers", str(max(1, len(sizes)))]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     if out.returncode == 0:
         per = json.loads(out.stdout.strip().splitlines()[-1])["logml_s_per_item_by_n"]
-        cores = os.cpu_count() or 1
+        from oracle.cpu_baseline import usable_cores      # CPU-baseline leg only
+        cores = usable_cores()[0]
         GRAD_FACTOR = 3.0
         cpu_core_s = 0.0
         for (kind, ns), (calls, items) in eng.trace.items():
@@ -484,7 +488,8 @@ def main():
         if fit_res is not None:
             res["fit_forecast"] = fit_res
         if not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            from oracle.cpu_baseline import usable_cores      # CPU-baseline leg only
+            cores = usable_cores()[0]
             per_item_s = {"C5": 12.0}.get(args.config, 0.5)       # rough, to bound the sample
             sample = args.cpu_sample or int(min(B, max(8, min(4 * cores, 20.0 * cores / per_item_s))))
             idx = sorted(set(int(i) for i in np.linspace(0, B - 1, sample)))

@@ -57,6 +57,35 @@ def _logml_size(arg):
     return ns, time.perf_counter() - t0
 
 
+def usable_cores():
+    """cores this process may actually run on: the affinity mask, cut to the cgroup's CPU quota
+    (cpu.max of cgroup v2, cfs_quota of v1) when there is one -- more busy workers than that only
+    take turns."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = float(f.read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="C3")
@@ -67,13 +96,19 @@ def main():
     ap.add_argument("--items", default="")
     ap.add_argument("--sizes", default="")
     ap.add_argument("--per-size", type=int, default=2)
-    ap.add_argument("--workers", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--workers", type=int, default=0,
+                    help="worker processes; 0 = every usable core (affinity mask and cgroup quota)")
+    ap.add_argument("--max-workers", type=int, default=0, help="cap on the automatic choice")
     ap.add_argument("--one-core-items", type=int, default=2,
                     help="items also timed on ONE worker (scaling 1 -> all cores)")
     a = ap.parse_args()
+    cores, quota = usable_cores()
+    if a.workers <= 0:
+        a.workers = min(cores, a.max_workers) if a.max_workers > 0 else cores
     init = (a.config, a.rank, a.n, a.particles, a.scenarios)
     ctx = mp.get_context("fork")          # this process never touches a GPU
-    out = {"workers": a.workers, "blas_threads_per_worker": 1}
+    out = {"workers": a.workers, "blas_threads_per_worker": 1, "usable_cores": cores,
+           "cgroup_cpu_quota": quota, "host_cores": os.cpu_count()}
     if a.items:
         idx = [int(x) for x in a.items.split(",")]
         with ctx.Pool(a.workers, initializer=_init, initargs=init) as pool:
