@@ -924,6 +924,14 @@ __device__ __forceinline__ void gemm_rows(double (&acc)[NA][4][4], const double 
 // order, written to a per-wave LDS tile and from there to HBM as full 512-byte rows.
 // LDS: M strips (32 KiB, shared) + 16 tile rows x 64 columns per wave and pass, pitch 66 doubles.
 // ---------------------------------------------------------------------------------------
+#ifdef NGP_PHASE_STAMPS
+#define NGP_STAMP(var) var = __builtin_amdgcn_s_memrealtime()
+// anchored: not before `dep` is computed, ordered with the memory operations around it
+#define NGP_STAMP_DEP(var, dep) \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) : "v"(dep) : "memory")
+#else
+#define NGP_STAMP(var)
+#endif
 constexpr int EPI_PITCH = 66;                       // doubles per LDS row (16-byte aligned rows)
 constexpr int EPI_M_BYTES = NB * NB * 8;            // M strips, shared by the workgroup's tiles
 constexpr int EPI_WAVE_BYTES = 16 * EPI_PITCH * 8;  // 16 tile rows x 64 columns per wave and pass
@@ -945,42 +953,70 @@ template <bool SHADOW = false>
 __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], double *Lr,
                                                     const double *lds_m, long ld, int kmax,
                                                     int lane, double *buf, float *Lr32 = nullptr,
-                                                    float *tmax_out = nullptr) {
+                                                    float *tmax_out = nullptr
+#ifdef NGP_PHASE_STAMPS
+                                                    , unsigned long long *dbg = nullptr
+#endif
+                                                    ) {
     double amax = 0.0;
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;          // row of S' inside a 16-tile
+    // K' of the next 16-row group is requested before this group's product starts, so that its
+    // round trip runs under the MFMAs (rows of different groups never overlap)
+    double kv[4][4];
+    auto load_k = [&](int it) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * it + ((n16 + 4 * r) & 15);
+                kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
+            }
+    };
+    load_k(0);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {                // 16 tile rows per pass
         double c4[4][4];   // C' = K' - S' for this 16-row group of the tile
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * it + ((n16 + 4 * r) & 15);
-                c4[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0] - acc4[jt][it][r];
+            for (int r = 0; r < 4; ++r) c4[jt][r] = kv[jt][r] - acc4[jt][it][r];
+#ifdef NGP_PHASE_STAMPS
+        if (dbg) NGP_STAMP_DEP(dbg[3 * it], c4[3][3] + c4[0][0] + c4[1][2] + c4[2][1]);
+#endif
+        if (it + 1 < 4) load_k(it + 1);
+        // 16 strip groups cb4 = 4 ct + cq (output rows 4 cb4 ..: C' tiles jt <= ct).  The M strips of
+        // group cb4 + 1 are requested before the result of group cb4 is written to the LDS tile:
+        // behind that write hipcc would not move them (same LDS array), and every group would
+        // wait out an LDS round trip before its first MFMA (15 us of a tile's 22, fat_phases.py)
+        double ms[2][4];
+        ms[0][0] = lds_m[lane];
+#pragma unroll
+        for (int cb4 = 0; cb4 < 16; ++cb4) {
+            const int ct = cb4 >> 2;
+            if (cb4 + 1 < 16) {
+#pragma unroll
+                for (int jt = 0; jt <= ((cb4 + 1) >> 2); ++jt)
+                    ms[(cb4 + 1) & 1][jt] = lds_m[((cb4 + 1) * 4 + jt) * 64 + lane];
             }
+            double R[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {            // output rows 16 ct ..: C' tiles jt <= ct
+            for (int jt = 0; jt <= ct; ++jt) {
 #pragma unroll
-            for (int cq = 0; cq < 4; ++cq) {
-                const int cb4 = 4 * ct + cq;
-                double R[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int jt = 0; jt <= ct; ++jt) {
-                    const double a = lds_m[(cb4 * 4 + jt) * 64 + lane];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) R[r] = mfma4(a, c4[jt][r], R[r]);
-                }
-                // lane group b of R[r] holds the partial sum for tile rows 4 ((b + r) & 3) ..:
-                // rotating R[r] by r lane groups lines all four partial sums up on the lanes
-                // i = n16, where they are added (fixed order: deterministic)
-                double x = R[0];
-                x += dpp_f64<ROW_ROR4, 0xF>(R[1], R[1]);
-                x += dpp_f64<ROW_ROR8, 0xF>(R[2], R[2]);
-                x += dpp_f64<ROW_ROR12, 0xF>(R[3], R[3]);
-                buf[n16 * EPI_PITCH + 4 * cb4 + isub] = x;   // X'[c = 4 cb4 + isub][i = 16 it + n16]
+                for (int r = 0; r < 4; ++r) R[r] = mfma4(ms[cb4 & 1][jt], c4[jt][r], R[r]);
             }
+            // lane group b of R[r] holds the partial sum for tile rows 4 ((b + r) & 3) ..:
+            // rotating R[r] by r lane groups lines all four partial sums up on the lanes
+            // i = n16, where they are added (fixed order: deterministic)
+            double x = R[0];
+            x += dpp_f64<ROW_ROR4, 0xF>(R[1], R[1]);
+            x += dpp_f64<ROW_ROR8, 0xF>(R[2], R[2]);
+            x += dpp_f64<ROW_ROR12, 0xF>(R[3], R[3]);
+            buf[n16 * EPI_PITCH + 4 * cb4 + isub] = x;   // X'[c = 4 cb4 + isub][i = 16 it + n16]
         }
+#ifdef NGP_PHASE_STAMPS
+        if (dbg) NGP_STAMP_DEP(dbg[3 * it + 1], it);
+#endif
         // rows 16 it .. 16 it + 15 of the tile: 32 lanes x 16 B per 512-byte row
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
@@ -996,6 +1032,9 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
                 amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
             }
         }
+#ifdef NGP_PHASE_STAMPS
+        if (dbg) NGP_STAMP_DEP(dbg[3 * it + 2], it);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (SHADOW) {
@@ -1006,20 +1045,38 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
     }
 }
 
-// tile[i][c0 + jj] -= S'[jj][i], straight from the 4x4x4 register layout
+// tile[i][c0 + jj] -= S'[jj][i], straight from the 4x4x4 register layout.  The 16 elements a lane
+// owns in a 16-row group are loaded together and the next group is requested before this one is
+// written back: written as `*e -= x` per element, hipcc orders every load behind the previous
+// store (64 dependent round trips per tile: 35 us of a fat workgroup's 270, scripts/fat_phases.py).
 __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, int c0,
                                                        const double (*acc4)[4][4], int lane) {
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;
+    double *base = rows + c0 + jj0;
+    long roff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) roff[r] = (long)((n16 + 4 * r) & 15) * ld;
+    double v[2][4][4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-        for (int it = 0; it < 4; ++it)
+        for (int r = 0; r < 4; ++r) v[0][jt][r] = base[roff[r] + 16 * jt];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *e = rows + (long)(16 * it + ((n16 + 4 * r) & 15)) * ld + c0 + 16 * jt + jj0;
-                *e -= acc4[jt][it][r];
-            }
+    for (int it = 0; it < 4; ++it) {
+        if (it + 1 < 4) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    v[(it + 1) & 1][jt][r] = base[(long)(16 * (it + 1)) * ld + roff[r] + 16 * jt];
+        }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                base[(long)(16 * it) * ld + roff[r] + 16 * jt] = v[it & 1][jt][r] - acc4[jt][it][r];
+    }
 }
 
 struct ColStep {
@@ -1102,6 +1159,123 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// THIN step (column j of a pair: only k in [64 (j-1), 64 j) is left).  One row tile per wave, as in
+// chol_col_kernel, but nothing of the operand traffic waits on a register: the 64 x 64 block of
+// panel rows all four waves multiply against and the M strips of the epilogue go HBM -> LDS by
+// LDS-DMA at kernel entry, and the wave's own 64 x 64 operand block is requested four 8-deep
+// stages ahead (the direct-load kernel, at 256 VGPRs, could keep two in flight and spent most of
+// its k-loop waiting: MFMA pipe 42 % busy, profiles/r02/clock_C3.txt).  Same MFMA order as
+// gemm_rows: results are bit-identical to the direct-load kernel.
+// LDS: M strips 32 KiB | panel block 32 KiB (64 rows x 512 B; 16-byte piece p of row r sits in
+// slot p ^ (r & 7), swizzled on the source address), reused for the per-wave epilogue tiles.
+// ---------------------------------------------------------------------------------------
+template <bool MIXED>
+__global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkPtrs p, int Bc,
+                                                               ColStep st) {
+    constexpr int A_BYTES = NB * NB * 8;
+    constexpr int TAIL = (4 * EPI_WAVE_BYTES > A_BYTES) ? 4 * EPI_WAVE_BYTES : A_BYTES;
+    __shared__ __attribute__((aligned(1024))) char smem[EPI_M_BYTES + TAIL];
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7, idx = wg >> 3;   // blocks b and b+8 share an XCD (speed only)
+    const int slot = (idx / st.groups) * 8 + xcd;
+    const int grp = idx % st.groups;
+    if (slot >= Bc) return;                  // whole workgroup, before any barrier
+    const int item = p.items ? p.items[slot] : slot;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = grp * 4 + wave;
+    bool valid = tile < st.ntiles;
+    const int j = st.j;
+    const int kmax = j * NB, k0 = kmax - NB;
+    // gradient jobs: identity tile a is zero left of block column a — tile a == j has nothing to
+    // subtract (its k-range would start at 64 j), tiles a > j are still zero
+    bool update = true;
+    if (g.aux_identity && valid && tile >= st.nmain) {
+        const int a = tile - st.nmain;
+        if (a < g.nb0) {
+            if (a > j) valid = false;
+            else if (a * NB > k0) update = false;
+        }
+    }
+    const long ld = g.ld;
+    double *Lit = p.L + (long)item * g.item_stride;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    // ---- LDS-DMA: panel block (rows 64 j .. 64 j + 63, columns k0 .. k0 + 63) and M strips ----
+    {
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+            Lit, 0, (int)(g.item_stride * (long)sizeof(double)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+            p.dinv + (long)item * (NB * NB), 0, NB * NB * 8, 0x00020000);
+        // instruction i of wave w: rows 2 (8 w + i), + 1; lane = (row bit, slot); piece = slot ^ key
+        const int rbit = lane >> 5, sl = lane & 31;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int key = (2 * i + rbit) & 7;
+            const unsigned voff = (unsigned)((rbit * ld + 2 * (sl ^ key)) * 8);
+            const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(
+                (int)((((long)kmax + 2 * (8 * wave + i)) * ld + k0) * 8));
+            lds_ptr dst = (lds_ptr)(smem + EPI_M_BYTES + (8 * wave + i) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, dst, 16, voff, soff, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            lds_ptr dst = (lds_ptr)(smem + (8 * wave + i) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rm, dst, 16, (unsigned)(lane * 16),
+                                                     (unsigned)((8 * wave + i) * 1024), 0, 0);
+        }
+    }
+
+    double acc4[4][4][4];  // [jt][it][r], see mfma16_as_4
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
+
+    const int vt = valid ? tile : 0;
+    const long rowbase = (vt < st.nmain) ? (long)(j + 1 + vt) * NB
+                                         : (long)g.n0 + (long)(vt - st.nmain) * NB;
+    double *Lr = Lit + rowbase * ld;
+    const double *pb = Lr + (long)r16 * ld + k0 + 2 * q;   // B operand: rows of this tile
+    const bool mult = valid && update;
+    Frag8<4> b[4];
+    if (mult) {
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) load_frag8(b[sg], pb + 8 * sg, ld);
+    }
+    __syncthreads();   // the LDS-DMA of every wave has landed (hipcc drains vmcnt ahead of it)
+    if (mult) {
+        const char *Ab = smem + EPI_M_BYTES + r16 * 512;
+        const int key = r16 & 7;
+#pragma unroll
+        for (int sg = 0; sg < 8; ++sg) {
+            Frag8<4> a;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                a.v[u] = *reinterpret_cast<const f64x2 *>(Ab + u * (16 * 512) +
+                                                          (((4 * sg + q) ^ key) << 4));
+            mfma_frag8(acc4, a, b[sg & 3]);
+            if (sg + 4 < 8) load_frag8(b[sg & 3], pb + 8 * (sg + 4), ld);
+        }
+    }
+    __syncthreads();   // the panel block is dead: its LDS becomes the per-wave epilogue tiles
+    if (!valid) return;
+    double *buf = reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES);
+    if constexpr (MIXED) {
+        const int rt = (tile < st.nmain) ? j + 1 + tile : g.nb0 + (tile - st.nmain);
+        solve_and_store_lds<true>(
+            acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane, buf,
+            p.L32 + (long)item * g.item_stride + rowbase * ld,
+            p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
+    } else {
+        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane, buf);
+    }
+}
+
 constexpr int LDS_KC = 16;   // k-depth of one staged chunk
 
 // ---------------------------------------------------------------------------------------
@@ -1139,6 +1313,16 @@ constexpr int LDS_KC = 16;   // k-depth of one staged chunk
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef NGP_PHASE_STAMPS
+// Diagnostic build only (scripts/fat_phases.py; never defined for libngp.so): every wave of the
+// fat step whose block column is ngp_stamp_j leaves 100-MHz timestamps of its phases and the CU /
+// SIMD it ran on.
+constexpr int STAMP_WORDS = 32;
+__device__ unsigned long long *ngp_stamps = nullptr;
+__device__ unsigned int ngp_stamp_count = 0, ngp_stamp_cap = 0;
+__device__ int ngp_stamp_j = -1;
+#endif
+
 template <bool MIXED>
 __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                                ColStep st) {
@@ -1167,6 +1351,11 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     bool valid = tile < st.ntiles;
 
     const int j = st.j;
+#ifdef NGP_PHASE_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts6 = 0, ts7 = 0;
+    unsigned long long tc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    NGP_STAMP(ts0);
+#endif
     const long ld = g.ld;
     double *Lit = p.L + (long)item * g.item_stride;
     const int kmax = j * NB;
@@ -1243,7 +1432,8 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
 
-    // one 16-deep fp64 chunk in buffer `buf`: 256 mfma4 per wave
+    // one 16-deep fp64 chunk in buffer `buf`: 256 mfma4 per wave.  (Requesting the operands of
+    // k-step s+1 before the MFMAs of k-step s — two register sets — measured 1 % slower.)
     auto mult64 = [&](const char *buf) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1274,6 +1464,10 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
                 if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
                 mult64(smem + cur * STAGE);
                 __syncthreads();
+#ifdef NGP_PHASE_STAMPS
+                if (c == 0) NGP_STAMP(ts1);
+                if (c == nchunks / 2) NGP_STAMP(ts2);
+#endif
             }
         }
     } else {
@@ -1467,8 +1661,10 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     // the staging buffers are free (every wave passed the k-loop's last barrier): M strips go to
     // LDS for both tiles of the workgroup
     static_assert(EPI_LDS_BYTES <= 2 * STAGE, "epilogue LDS must fit the stage buffers");
+    NGP_STAMP(ts3);
     stage_mstrips(reinterpret_cast<double *>(smem), p.dinv + (long)item * (NB * NB), tid);
     __syncthreads();
+    NGP_STAMP(ts4);
     if (!valid) return;
 
     double *Lr = Lit + tile_row0(tile) * ld;
@@ -1483,9 +1679,61 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
             p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
     } else {
         solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
-                            reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES));
+                            reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES)
+#ifdef NGP_PHASE_STAMPS
+                            , nullptr, nullptr, tc
+#endif
+                            );
     }
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP(ts5);
+    __builtin_amdgcn_s_waitcnt(0);       // stores retired (vmcnt(0))
+    NGP_STAMP(ts6);
+    if (j == ngp_stamp_j && lane == 0) {
+        const unsigned idx = atomicAdd(&ngp_stamp_count, 1u);
+        if (idx < ngp_stamp_cap) {
+            unsigned long long *o = ngp_stamps + (size_t)idx * STAMP_WORDS;
+            const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            o[0] = ((unsigned long long)xcc << 32) | hwid;
+            o[1] = ((unsigned long long)wg << 8) | (unsigned)wave;
+            o[2] = ts0; o[3] = ts1; o[4] = ts2; o[5] = ts3; o[6] = ts4; o[7] = ts5; o[8] = ts6;
+            o[9] = (unsigned long long)item; o[10] = (unsigned long long)tile; o[11] = ts7;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) o[12 + i] = tc[i];
+        }
+    }
+#endif
 }
+
+#ifdef NGP_PHASE_STAMPS
+}  // namespace ngp
+extern "C" int ngp_dbg_stamps_begin(int j, unsigned cap) {
+    unsigned long long *buf = nullptr;
+    if (hipMalloc(&buf, (size_t)cap * ngp::STAMP_WORDS * 8) != hipSuccess) return 1;
+    (void)hipMemset(buf, 0, (size_t)cap * ngp::STAMP_WORDS * 8);
+    unsigned zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ngp::ngp_stamps), &buf, sizeof(buf));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ngp::ngp_stamp_count), &zero, sizeof(zero));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ngp::ngp_stamp_cap), &cap, sizeof(cap));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ngp::ngp_stamp_j), &j, sizeof(j));
+    return 0;
+}
+extern "C" long ngp_dbg_stamps_fetch(unsigned long long *out, unsigned cap) {
+    (void)hipDeviceSynchronize();
+    unsigned n = 0;
+    unsigned long long *buf = nullptr;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(ngp::ngp_stamp_count), sizeof(n));
+    (void)hipMemcpyFromSymbol(&buf, HIP_SYMBOL(ngp::ngp_stamps), sizeof(buf));
+    if (n > cap) n = cap;
+    (void)hipMemcpy(out, buf, (size_t)n * ngp::STAMP_WORDS * 8, hipMemcpyDeviceToHost);
+    int off = -1;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ngp::ngp_stamp_j), &off, sizeof(off));
+    (void)hipFree(buf);
+    return (long)n;
+}
+namespace ngp {
+#endif
 
 // order[slot] = the item with the slot-th largest number of fp64 tile products since the previous
 // call (mixcnt[2 i + 1] counts them; prev keeps the snapshot), ties by index.  One workgroup.
@@ -2734,6 +2982,14 @@ void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int mo
         else
             hipLaunchKernelGGL(chol_col_glds_kernel<false>, dim3(st.groups * bpad), dim3(256), 0, s,
                                g, p, Bc, st);
+    } else if (mode == COL_THIN && k0 == j * NB - NB && j > 0) {
+        st.groups = (st.ntiles + 3) / 4;
+        if (mixed)
+            hipLaunchKernelGGL(chol_col_thin_kernel<true>, dim3(st.groups * bpad), dim3(256), 0, s,
+                               g, p, Bc, st);
+        else
+            hipLaunchKernelGGL(chol_col_thin_kernel<false>, dim3(st.groups * bpad), dim3(256), 0,
+                               s, g, p, Bc, st);
     } else {
         st.groups = (st.ntiles + 3) / 4;
         if (mixed)

@@ -1,0 +1,129 @@
+"""Where the time of a fat step goes, wave by wave (diagnostic; not part of the product).
+
+Needs the diagnostic build (phase stamps compiled in; libngp.so never has them):
+
+    cd nowcastautogp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+        -DNGP_PHASE_STAMPS -o ../libngp_stamps.so ngp_kernels.hip ngp_api.hip
+    gpurun -- python3 scripts/fat_phases.py 15 16        # block column j, particles (x 200 scenarios)
+
+Every wave of the fat launch of block column j records 100-MHz timestamps (start, first chunk done,
+half of the k-loop, k-loop done, M strips staged, epilogue issued, stores retired) and the CU/SIMD it
+ran on; the table goes to gpurun_out/fat_phases_j<j>.npy and a summary to stdout.
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["NGP_LIB"] = os.path.join(ROOT, "nowcastautogp_amd", "libngp_stamps.so")
+import numpy as np
+
+from nowcastautogp_amd import _lib
+from nowcastautogp_amd.synthetic import bench_items
+
+WORDS = 32
+
+
+def analyse(a, j):
+    hw, ids = a[:, 0], a[:, 1]
+    xcc = (hw >> 32) & 0xF
+    h = hw & 0xFFFFFFFF
+    simd, cu, sh, se = (h >> 4) & 3, (h >> 8) & 15, (h >> 12) & 1, (h >> 13) & 7
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    wave = ids & 0xFF
+    t = a[:, 2:9].astype(np.int64)
+    t0 = t[:, 0].min()
+    t = (t - t0) * 0.01            # microseconds
+    col = wave & 1
+    print(f"j={j}: {len(a)} wave records, {len(np.unique(cuid))} CUs, launch span {t[:, 6].max():.0f} us")
+    names = ["start->chunk0", "chunk0->half", "half->k end", "k end->M staged", "M staged->issued",
+             "issued->retired"]
+    for c in (0, 1):
+        m = col == c
+        d = np.diff(t[m], axis=1)
+        print(f"  column-{c} waves ({m.sum()}):")
+        for k, nm in enumerate(names):
+            print(f"    {nm:>20s}: median {np.median(d[:, k]):7.2f}  p10 {np.percentile(d[:, k], 10):7.2f}"
+                  f"  p90 {np.percentile(d[:, k], 90):7.2f} us")
+        tot = t[m, 6] - t[m, 0]
+        print(f"    {'whole wave':>20s}: median {np.median(tot):7.2f} us")
+    m0 = (col == 0) & (a[:, 12] != 0)
+    if m0.any():
+        tc = (a[m0, 12:24].astype(np.int64) - t0) * 0.01
+        tc = tc.reshape(-1, 4, 3)
+        tm = t[m0]
+        print("  column-0 epilogue, per 16-row pass (us, median): K' arrived | product + LDS | stores issued")
+        prev = tm[:, 4]
+        for it in range(4):
+            print(f"    pass {it}: {np.median(tc[:, it, 0] - prev):6.2f} | "
+                  f"{np.median(tc[:, it, 1] - tc[:, it, 0]):6.2f} | "
+                  f"{np.median(tc[:, it, 2] - tc[:, it, 1]):6.2f}")
+            prev = tc[:, it, 2]
+    # per SIMD: is the k-loop of a wave faster while its partner is outside its own k-loop?
+    kbeg, kend, wend = t[:, 1], t[:, 3], t[:, 6]
+    key = cuid * 4 + simd
+    order = np.argsort(key, kind="stable")
+    rate_alone, rate_shared = [], []
+    nchunk = 4 * j
+    for k in np.unique(key)[:256]:
+        idx = order[np.searchsorted(key[order], k, "left"):np.searchsorted(key[order], k, "right")]
+        for i in idx:
+            # fraction of wave i's k-loop during which some other wave of the SIMD is in its k-loop
+            ov = 0.0
+            for o in idx:
+                if o != i:
+                    ov += max(0.0, min(kend[i], kend[o]) - max(kbeg[i], kbeg[o]))
+            dur = kend[i] - kbeg[i]
+            (rate_shared if ov / dur > 0.9 else rate_alone if ov / dur < 0.6 else []).append(dur)
+    if rate_shared:
+        print(f"  k-loop (chunk 1..{nchunk}) wall time: partner in its k-loop >90% of it: "
+              f"median {np.median(rate_shared):.1f} us ({len(rate_shared)} waves); <60%: "
+              f"{np.median(rate_alone) if rate_alone else float('nan'):.1f} us ({len(rate_alone)} waves)")
+    # idle estimate per SIMD: time inside the launch span when no resident wave is in a k-loop
+    idle = []
+    for k in np.unique(key)[:512]:
+        idx = order[np.searchsorted(key[order], k, "left"):np.searchsorted(key[order], k, "right")]
+        ev = sorted([(t[i, 0], 1) for i in idx] + [(kend[i], -1) for i in idx])
+        lo, hi = min(t[i, 0] for i in idx), max(wend[i] for i in idx)
+        busy, depth, last = 0.0, 0, lo
+        for x, s in ev:
+            if depth > 0:
+                busy += x - last
+            depth += s
+            last = x
+        idle.append(1.0 - busy / (hi - lo))
+    print(f"  share of a SIMD's time with NO resident wave inside its k-loop: median {np.median(idle):.3f}"
+          f" (p10 {np.percentile(idle, 10):.3f}, p90 {np.percentile(idle, 90):.3f})")
+    resid = []
+    for k in np.unique(key)[:512]:
+        idx = order[np.searchsorted(key[order], k, "left"):np.searchsorted(key[order], k, "right")]
+        lo, hi = min(t[i, 0] for i in idx), max(wend[i] for i in idx)
+        resid.append(sum(wend[i] - t[i, 0] for i in idx) / (hi - lo))
+    print(f"  resident waves per SIMD (time average): {np.mean(resid):.2f}")
+
+
+def main():
+    j = int(sys.argv[1]) if len(sys.argv) > 1 else 15
+    P = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    lib = C.CDLL(os.environ["NGP_LIB"])
+    ctx = _lib.Context(0)
+    w, progs, Y, tt = bench_items("C3", 0, None, P, None)
+    job = ctx.stage_predict(progs, tt, Y, w.t_new)
+    job.run()                                   # warm
+    cap = len(progs) * 20 * 4
+    assert lib.ngp_dbg_stamps_begin(C.c_int(j), C.c_uint(cap)) == 0
+    job.run()
+    out = job.fetch()
+    buf = np.zeros((cap, WORDS), np.uint64)
+    lib.ngp_dbg_stamps_fetch.restype = C.c_long
+    n = lib.ngp_dbg_stamps_fetch(buf.ctypes.data_as(C.c_void_p), C.c_uint(cap))
+    a = buf[:n]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    np.save(os.path.join(ROOT, "gpurun_out", f"fat_phases_j{j}.npy"), a)
+    print("items", len(progs), "failed", int(np.count_nonzero(out["info"])), "records", n)
+    analyse(a, j)
+
+
+if __name__ == "__main__":
+    main()
