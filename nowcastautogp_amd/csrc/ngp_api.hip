@@ -137,6 +137,11 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
     }
     int nr = 0, ntab = 0;
     struct RFrame { int node, stage; };
+    auto new_table = [&](int node) {
+        out->tb_first[ntab] = (uint8_t)dev_first[(size_t)node];
+        out->tb_last[ntab] = (uint8_t)dev_index[(size_t)node];
+        return ntab++;
+    };
     std::vector<RFrame> rs{{stack.back(), 0}};
     while (!rs.empty()) {
         RFrame &f = rs.back();
@@ -144,10 +149,7 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
         const int di = dev_index[(size_t)f.node];
         if (stat[(size_t)f.node]) {
             out->rops[nr] = (uint8_t)OP_TABLE;
-            out->rslot[nr] = (uint8_t)ntab;
-            out->tb_first[ntab] = (uint8_t)dev_first[(size_t)f.node];
-            out->tb_last[ntab] = (uint8_t)di;
-            ++ntab;
+            out->rslot[nr] = (uint8_t)new_table(f.node);
             ++nr;
             rs.pop_back();
         } else if (nd.op < NGP_OP_PLUS) {   // Linear
@@ -157,14 +159,26 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
             rs.pop_back();
         } else {
             const bool swap = nodes[(size_t)nd.right].need > nodes[(size_t)nd.left].need;
+            const int second = swap ? nd.left : nd.right;
+            const bool leaf2 = stat[(size_t)second] || nodes[(size_t)second].op == NGP_OP_LINEAR;
             if (f.stage == 0) {
                 f.stage = 1;
                 rs.push_back({swap ? nd.right : nd.left, 0});
-            } else if (f.stage == 1) {
+            } else if (f.stage == 1 && !leaf2) {
                 f.stage = 2;
-                rs.push_back({swap ? nd.left : nd.right, 0});
+                rs.push_back({second, 0});
             } else {
-                out->rops[nr] = out->ops[di];       // Plus / Times / ChangePoint or its swapped form
+                int code = out->ops[di];            // Plus / Times / ChangePoint or its swapped form
+                if (leaf2) {                        // the second operand rides along (never pushed)
+                    if (stat[(size_t)second]) {
+                        code |= RLEAF_TABLE << 4;
+                        out->rleaf[nr] = (uint8_t)new_table(second);
+                    } else {
+                        code |= RLEAF_LINEAR << 4;
+                        out->rleaf[nr] = out->poff[dev_index[(size_t)second]];
+                    }
+                }
+                out->rops[nr] = (uint8_t)code;
                 out->rslot[nr] = out->slot[di];
                 out->rpoff[nr] = out->poff[di];
                 ++nr;
@@ -174,6 +188,9 @@ ngp_status compile_program(const ngp_kernel *k, DevProgram *out, std::vector<int
     }
     out->n_rops = nr;
     out->n_tab = ntab;
+    out->rchain = 1;
+    for (int i = 1; i < nr; ++i)
+        if ((out->rops[i] >> 4) == 0) out->rchain = 0;
     if (n_tab) *n_tab = ntab;
     return NGP_OK;
 }
@@ -406,6 +423,10 @@ struct ngp_job {
     std::vector<void *> owned;
     // the spec the job was staged under: a later ngp_set_spec does not reach a staged job
     ngp_spec spec{};
+    // lattice jobs: items whose reduced program is a chain of more than one instruction / the other
+    // items (ascending job-wide indices; device copies fill_chain_d / fill_other_d)
+    std::vector<int32_t> fill_chain, fill_other;
+    int32_t *fill_chain_d = nullptr, *fill_other_d = nullptr;
     // NGP_PREC_MIXED: per item, filled by ngp_job_run
     std::vector<int32_t> refine_steps;
     std::vector<double> refine_delta, frac32;
@@ -661,6 +682,16 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     CPY(j->y0, h_y0.data(), ny * g.n0, double);
     CPY(j->ya, h_ya.data(), (int64_t)ny * D * g.da, double);
     if (g.lattice) CPY(j->qpts, h_q.data(), g.npts, int32_t);
+    if (g.lattice && g.n0 > 0) {
+        for (int i = 0; i < P; ++i)
+            (hp[(size_t)i].rchain && hp[(size_t)i].n_rops > 1 ? j->fill_chain : j->fill_other)
+                .push_back(i);
+        if ((st = job_alloc(j, &j->fill_chain_d, std::max<size_t>(j->fill_chain.size(), 1))) ||
+            (st = job_alloc(j, &j->fill_other_d, std::max<size_t>(j->fill_other.size(), 1))))
+            return fail(st);
+        CPY(j->fill_chain_d, j->fill_chain.data(), j->fill_chain.size(), int32_t);
+        CPY(j->fill_other_d, j->fill_other.data(), j->fill_other.size(), int32_t);
+    }
 #undef CPY
     if (hipStreamSynchronize(s) != hipSuccess) return fail(NGP_ERR_STATE);
     *out = j;
@@ -843,6 +874,18 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
             p.tab = (double *)tab;
             p.sig = (double *)sig;
             p.qpts = j->qpts;
+            if (j->fill_other_d) {   // the chunk's share of the two item lists
+                auto range = [&](const std::vector<int32_t> &v, const int32_t *dev,
+                                 const int32_t **ptr, int32_t *cnt) {
+                    const auto lo = std::lower_bound(v.begin(), v.end(), b0);
+                    const auto hi = std::lower_bound(v.begin(), v.end(), b0 + bc);
+                    *ptr = dev + (lo - v.begin());
+                    *cnt = (int32_t)(hi - lo);
+                };
+                range(j->fill_chain, j->fill_chain_d, &p.fill_chain, &p.n_fill_chain);
+                range(j->fill_other, j->fill_other_d, &p.fill_other, &p.n_fill_other);
+                p.fill_base = b0;
+            }
             if (mixed) {
                 p.L32 = (float *)L32;
                 p.tmax = (float *)tmx;

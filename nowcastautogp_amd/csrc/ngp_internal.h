@@ -18,6 +18,7 @@ constexpr int OP_CP_SWAPPED = 9;
 // reduced program only: a whole stationary subtree (no Linear, no ChangePoint below it) read from
 // its table by lattice distance
 constexpr int OP_TABLE = 10;
+constexpr int RLEAF_TABLE = 1, RLEAF_LINEAR = 2;   // DevProgram::rops >> 4
 constexpr int MAX_TABLES = NGP_MAX_OPS / 2;   // a tree of NGP_MAX_OPS nodes has at most that many leaves
 
 // One particle's kernel, flattened for the device.  Copied into LDS by every workgroup that
@@ -34,10 +35,17 @@ struct DevProgram {
     // Reduced program for value jobs on lattice times: every maximal stationary subtree is ONE
     // table leaf (its value depends on |t1 - t2| only, so tables_kernel evaluates the subtree once
     // per lattice distance — the same operations in the same order as element by element).
+    // A binary operation whose second operand is a leaf carries that leaf with it (high nibble of
+    // rops: RLEAF_TABLE / RLEAF_LINEAR, rleaf = its table slot / parameter offset): the operation
+    // then works on the top of the stack in place — a left-deep tree never moves the stack at all.
+    // Same operands, same operation: the value is bit-identical to the unfused evaluation.
     int32_t n_rops, n_tab;
-    uint8_t rops[NGP_MAX_OPS];          // NGP_OP_LINEAR, OP_TABLE, Plus / Times / ChangePoint (+ swapped)
+    int32_t rchain, rpad_;              // rchain: the reduced program pushes once (its first
+                                        // instruction) and every other instruction carries its leaf
+    uint8_t rops[NGP_MAX_OPS];          // low nibble: NGP_OP_LINEAR, OP_TABLE, Plus / Times / ChangePoint (+ swapped)
     uint8_t rslot[NGP_MAX_OPS];         // OP_TABLE: table slot; ChangePoint: sigmoid slot (= slot[] of the op)
     uint8_t rpoff[NGP_MAX_OPS];         // Linear / ChangePoint: offset of the parameters
+    uint8_t rleaf[NGP_MAX_OPS];         // fused leaf: table slot (RLEAF_TABLE) or parameter offset (RLEAF_LINEAR)
     uint8_t tb_first[MAX_TABLES];       // table k tabulates ops[tb_first[k] .. tb_last[k]] (a postfix
     uint8_t tb_last[MAX_TABLES];        //  range of the full program = one subtree)
 };
@@ -98,6 +106,11 @@ struct ChunkPtrs {
     unsigned     *mixcnt; // [Bc][2] tile products of the fat steps that ran in fp32 / in fp64
     double       *auxX;   // [Bc][naux_pad][n0] the fill also leaves the aux rows X here
     const int32_t *order; // mixed fat steps: dispatch order of the items (heaviest first) or null
+    // staged value jobs on a lattice: the chunk's items split by the shape of their reduced program
+    // (job-wide indices, ascending; item of the chunk = entry - fill_base); null: every item goes
+    // through the general fill
+    const int32_t *fill_chain, *fill_other;
+    int32_t n_fill_chain, n_fill_other, fill_base;
     const int32_t *items; // refinement sweeps: the items (indices into the chunk) a launch works
                           // on, Bc = their count; null: all of them in order
 };

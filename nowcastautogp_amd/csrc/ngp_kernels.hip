@@ -444,34 +444,51 @@ __device__ __forceinline__ double keval_reduced(const DevProgram &P, const doubl
     const int nops = P.n_rops;
     if (nops == 1 && P.rops[0] == OP_TABLE) return tab[dq];   // the whole tree is stationary
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+    auto linear = [&](int pi) {
+        const double c = P.params[pi];
+        return P.params[pi + 1] + P.params[pi + 2] * (t1 - c) * (t2 - c);
+    };
     for (int i = 0; i < nops; ++i) {
-        const int op = __builtin_amdgcn_readfirstlane((int)P.rops[i]);
+        const int code = __builtin_amdgcn_readfirstlane((int)P.rops[i]);
+        const int op = code & 15, lk = code >> 4;
         if (op == OP_TABLE || op == NGP_OP_LINEAR) {
             double v;
             if (op == OP_TABLE) {
                 const int slot = __builtin_amdgcn_readfirstlane((int)P.rslot[i]);
                 v = tab[(long)slot * R + dq];
             } else {
-                const int pi = __builtin_amdgcn_readfirstlane((int)P.rpoff[i]);
-                const double c = P.params[pi];
-                v = P.params[pi + 1] + P.params[pi + 2] * (t1 - c) * (t2 - c);
+                v = linear(__builtin_amdgcn_readfirstlane((int)P.rpoff[i]));
             }
             s7 = s6; s6 = s5; s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v;
         } else {
+            // operands in evaluation order: a (first), b (second — the fused leaf if there is one)
+            double a, b;
+            if (lk) {
+                const int lf = __builtin_amdgcn_readfirstlane((int)P.rleaf[i]);
+                a = s0;
+                b = (lk == RLEAF_TABLE) ? tab[(long)lf * R + dq] : linear(lf);
+            } else {
+                a = s1;
+                b = s0;
+            }
             double v;
             if (op == NGP_OP_PLUS) {
-                v = s1 + s0;
+                v = a + b;
             } else if (op == NGP_OP_TIMES) {
-                v = s1 * s0;
+                v = a * b;
             } else {
                 const int slot = __builtin_amdgcn_readfirstlane((int)P.rslot[i]);
-                const double kl = (op == NGP_OP_CHANGEPOINT) ? s1 : s0;
-                const double kr = (op == NGP_OP_CHANGEPOINT) ? s0 : s1;
+                const double kl = (op == NGP_OP_CHANGEPOINT) ? a : b;
+                const double kr = (op == NGP_OP_CHANGEPOINT) ? b : a;
                 const double g1 = sig[(long)slot * npts + pt1];
                 const double g2 = sig[(long)slot * npts + pt2];
                 v = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
             }
-            s0 = v; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+            if (lk) {
+                s0 = v;
+            } else {
+                s0 = v; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = s6; s6 = s7;
+            }
         }
     }
     return s0;
@@ -485,7 +502,8 @@ template <bool GRADJOB>
 __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs p, int ntri,
                                                            int tile_off, int split, DevSpec sp) {
     __shared__ DevProgram P;
-    const int item = blockIdx.y;
+    // p.fill_other (staged value jobs): the chunk's items that are not chain programs
+    const int item = p.fill_other ? p.fill_other[blockIdx.y] - p.fill_base : (int)blockIdx.y;
     load_program(&P, p.progs + item);
     __syncthreads();
     const int tile = blockIdx.x / split + tile_off, sub = blockIdx.x % split;
@@ -550,6 +568,149 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
                 v.x = y0[col];
                 v.y = y0[col + 1];
             } else {
+                v.x = 0.0;
+                v.y = 0.0;
+            }
+        }
+        *reinterpret_cast<f64x2 *>(Lit + row * g.ld + col) = v;
+        if (aux && p.auxX)   // mixed-precision jobs keep the untouched aux rows X for the refinement
+            *reinterpret_cast<f64x2 *>(p.auxX + ((long)item * g.naux_pad + (row - g.n0)) * g.ld + col) = v;
+    }
+}
+
+// Chain programs (DevProgram::rchain with more than one instruction: one push, then only operations
+// that carry their leaf — 17 of the 19 non-stationary base kernels of the bench ensemble): every
+// instruction is decoded once per thread and applied to its 16 elements.  Same formulas and the
+// same order of operations per element as keval_reduced: bit-identical values.  A kernel of its own
+// (238 VGPRs would cost the single-lookup fill of stationary kernels its occupancy); `items` lists
+// the chunk's chain items (ChunkPtrs::fill_chain).
+__global__ __launch_bounds__(256) void fill_chain_kernel(JobGeom g, ChunkPtrs p, int ntri,
+                                                         DevSpec sp) {
+    __shared__ DevProgram P;
+    const int item = p.fill_chain[blockIdx.y] - p.fill_base;
+    load_program(&P, p.progs + item);
+    __syncthreads();
+    const int tile = blockIdx.x;
+    int r, c;
+    bool aux = false;
+    if (tile < ntri) {
+        r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+        while (r * (r + 1) / 2 > tile) --r;
+        c = tile - r * (r + 1) / 2;
+    } else {
+        const int a = tile - ntri;
+        r = a / g.nb0;
+        c = a % g.nb0;
+        aux = true;
+    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = c * NB + 2 * tx;
+    const double t2a = p.t0[col], t2b = p.t0[col + 1];
+    const int q2a = p.qpts[col], q2b = p.qpts[col + 1];
+    const double diag = P.noise + sp.jitter;
+    double *Lit = p.L + (long)item * g.item_stride;
+    const double *tab = p.tab + (long)item * g.maxstat * g.R;
+    const double *sig = p.sig + (long)item * g.maxcp * g.npts;
+    const int naux_t = g.da + g.m;
+    const double *y0 = p.y0 + (g.y_shared ? 0 : (long)item * g.n0);
+    // lattice data of the thread's 8 rows (aux rows past the last time point: any valid point,
+    // the value is not used)
+    int q1[8], pt1[8];
+    double t1[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int lr = ty * 8 + rr;
+        int pt = r * NB + lr;
+        if (aux) pt = (pt < naux_t) ? g.n0 + pt : 0;
+        pt1[rr] = pt;
+        q1[rr] = p.qpts[pt];
+        t1[rr] = pt < g.n0 ? p.t0[pt] : p.taux[pt - g.n0];
+    }
+    double kv[8][2];
+    const int nops = P.n_rops;
+    for (int i = 0; i < nops; ++i) {
+        const int code = __builtin_amdgcn_readfirstlane((int)P.rops[i]);
+        const int op = code & 15;
+        int lk = code >> 4, lf;
+        if (i == 0) {
+            lk = (op == OP_TABLE) ? RLEAF_TABLE : RLEAF_LINEAR;
+            lf = __builtin_amdgcn_readfirstlane((int)(op == OP_TABLE ? P.rslot[0] : P.rpoff[0]));
+        } else {
+            lf = __builtin_amdgcn_readfirstlane((int)P.rleaf[i]);
+        }
+        double b[8][2];
+        if (lk == RLEAF_TABLE) {
+            const double *tb = tab + (long)lf * g.R;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                b[rr][0] = tb[abs(q1[rr] - q2a)];
+                b[rr][1] = tb[abs(q1[rr] - q2b)];
+            }
+        } else {
+            const double cc = P.params[lf], b0 = P.params[lf + 1], b1 = P.params[lf + 2];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                b[rr][0] = b0 + b1 * (t1[rr] - cc) * (t2a - cc);
+                b[rr][1] = b0 + b1 * (t1[rr] - cc) * (t2b - cc);
+            }
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                kv[rr][0] = b[rr][0];
+                kv[rr][1] = b[rr][1];
+            }
+        } else if (op == NGP_OP_PLUS) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                kv[rr][0] = kv[rr][0] + b[rr][0];
+                kv[rr][1] = kv[rr][1] + b[rr][1];
+            }
+        } else if (op == NGP_OP_TIMES) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                kv[rr][0] = kv[rr][0] * b[rr][0];
+                kv[rr][1] = kv[rr][1] * b[rr][1];
+            }
+        } else {
+            const int slot = __builtin_amdgcn_readfirstlane((int)P.rslot[i]);
+            const double *sg = sig + (long)slot * g.npts;
+            const double g2a = sg[col], g2b = sg[col + 1];
+            const bool fwd = op == NGP_OP_CHANGEPOINT;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const double g1 = sg[pt1[rr]];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const double g2 = u ? g2b : g2a;
+                    const double kl = fwd ? kv[rr][u] : b[rr][u];
+                    const double kr = fwd ? b[rr][u] : kv[rr][u];
+                    kv[rr][u] = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int lr = ty * 8 + rr;
+        f64x2 v;
+        v.x = kv[rr][0];
+        v.y = kv[rr][1];
+        long row;
+        if (!aux) {
+            row = (long)r * NB + lr;
+            if (row == col) v.x += diag;
+            if (row == col + 1) v.y += diag;
+            if (row >= g.n_real || col >= g.n_real) v.x = (row == col) ? 1.0 : 0.0;
+            if (row >= g.n_real || col + 1 >= g.n_real) v.y = (row == col + 1) ? 1.0 : 0.0;
+        } else {
+            const int ar = r * NB + lr;
+            row = (long)g.n0 + ar;
+            if (ar == naux_t) {
+                v.x = y0[col];
+                v.y = y0[col + 1];
+            } else if (ar > naux_t) {
                 v.x = 0.0;
                 v.y = 0.0;
             }
@@ -2945,12 +3106,23 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
     if (g.lattice) {
         const long nwg = (long)(ntiles - off) * Bc;
         const int split = nwg <= 1024 ? 4 : (nwg <= 2048 ? 2 : 1);
-        if (p.dtab)
+        if (p.dtab) {
             hipLaunchKernelGGL(fill_lattice_kernel<true>, dim3((ntiles - off) * split, Bc), dim3(256),
                                0, s, g, p, ntri, off, split, sp);
-        else
+        } else if (p.fill_other && !aux_only) {
+            // staged value jobs: chain programs on their own kernel, the rest element by element
+            if (p.n_fill_other > 0)
+                hipLaunchKernelGGL(fill_lattice_kernel<false>, dim3(ntiles * split, p.n_fill_other),
+                                   dim3(256), 0, s, g, p, ntri, 0, split, sp);
+            if (p.n_fill_chain > 0)
+                hipLaunchKernelGGL(fill_chain_kernel, dim3(ntiles, p.n_fill_chain), dim3(256), 0, s,
+                                   g, p, ntri, sp);
+        } else {
+            ChunkPtrs q = p;
+            q.fill_other = nullptr;
             hipLaunchKernelGGL(fill_lattice_kernel<false>, dim3((ntiles - off) * split, Bc),
-                               dim3(256), 0, s, g, p, ntri, off, split, sp);
+                               dim3(256), 0, s, g, q, ntri, off, split, sp);
+        }
     }
     else
         hipLaunchKernelGGL(fill_kernel, dim3(ntiles - off, Bc), dim3(256), 0, s, g, p, ntri, off, sp);
