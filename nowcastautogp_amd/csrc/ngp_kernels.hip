@@ -1086,6 +1086,15 @@ __device__ __forceinline__ void gemm_rows(double (&acc)[NA][4][4], const double 
 // LDS: M strips (32 KiB, shared) + 16 tile rows x 64 columns per wave and pass, pitch 66 doubles.
 // ---------------------------------------------------------------------------------------
 #ifdef NGP_PHASE_STAMPS
+// Diagnostic build only (scripts/fat_phases.py; never defined for libngp.so): every wave of the
+// fat step whose block column is ngp_stamp_j leaves 100-MHz timestamps of its phases and the CU /
+// SIMD it ran on.
+constexpr int STAMP_WORDS = 32;
+__device__ unsigned long long *ngp_stamps = nullptr;
+__device__ unsigned int ngp_stamp_count = 0, ngp_stamp_cap = 0;
+__device__ int ngp_stamp_j = -1;
+#endif
+#ifdef NGP_PHASE_STAMPS
 #define NGP_STAMP(var) var = __builtin_amdgcn_s_memrealtime()
 // anchored: not before `dep` is computed, ordered with the memory operations around it
 #define NGP_STAMP_DEP(var, dep) \
@@ -1363,6 +1372,11 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
     const long ld = g.ld;
     double *Lit = p.L + (long)item * g.item_stride;
     const int r16 = lane & 15, q = lane >> 4;
+#ifdef NGP_PHASE_STAMPS
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts5 = 0, ts6 = 0;
+    unsigned long long tc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    NGP_STAMP_DEP(ts0, lane);
+#endif
 
     // ---- LDS-DMA: panel block (rows 64 j .. 64 j + 63, columns k0 .. k0 + 63) and M strips ----
     {
@@ -1409,6 +1423,9 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
         for (int sg = 0; sg < 4; ++sg) load_frag8(b[sg], pb + 8 * sg, ld);
     }
     __syncthreads();   // the LDS-DMA of every wave has landed (hipcc drains vmcnt ahead of it)
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(ts1, lane);
+#endif
     if (mult) {
         const char *Ab = smem + EPI_M_BYTES + r16 * 512;
         const int key = r16 & 7;
@@ -1423,7 +1440,13 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
             if (sg + 4 < 8) load_frag8(b[sg & 3], pb + 8 * (sg + 4), ld);
         }
     }
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(ts2, acc4[0][0][0] + acc4[3][3][3]);
+#endif
     __syncthreads();   // the panel block is dead: its LDS becomes the per-wave epilogue tiles
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(ts3, lane);
+#endif
     if (!valid) return;
     double *buf = reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES);
     if constexpr (MIXED) {
@@ -1433,8 +1456,31 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
             p.L32 + (long)item * g.item_stride + rowbase * ld,
             p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
     } else {
-        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane, buf);
+        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane, buf
+#ifdef NGP_PHASE_STAMPS
+                            , nullptr, nullptr, tc
+#endif
+                            );
     }
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(ts5, lane);
+    __builtin_amdgcn_s_waitcnt(0);
+    NGP_STAMP_DEP(ts6, lane);
+    if (j == -ngp_stamp_j && lane == 0) {     // thin steps are selected by a negative block column
+        const unsigned idx = atomicAdd(&ngp_stamp_count, 1u);
+        if (idx < ngp_stamp_cap) {
+            unsigned long long *o = ngp_stamps + (size_t)idx * STAMP_WORDS;
+            const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            o[0] = ((unsigned long long)xcc << 32) | hwid;
+            o[1] = ((unsigned long long)wg << 8) | (unsigned)wave;
+            o[2] = ts0; o[3] = ts1; o[4] = ts2; o[5] = ts3; o[6] = ts3; o[7] = ts5; o[8] = ts6;
+            o[9] = (unsigned long long)item; o[10] = (unsigned long long)tile; o[11] = 0;
+#pragma unroll
+            for (int i = 0; i < 18; ++i) o[12 + i] = tc[i];
+        }
+    }
+#endif
 }
 
 constexpr int LDS_KC = 16;   // k-depth of one staged chunk
@@ -1474,15 +1520,6 @@ constexpr int LDS_KC = 16;   // k-depth of one staged chunk
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifdef NGP_PHASE_STAMPS
-// Diagnostic build only (scripts/fat_phases.py; never defined for libngp.so): every wave of the
-// fat step whose block column is ngp_stamp_j leaves 100-MHz timestamps of its phases and the CU /
-// SIMD it ran on.
-constexpr int STAMP_WORDS = 32;
-__device__ unsigned long long *ngp_stamps = nullptr;
-__device__ unsigned int ngp_stamp_count = 0, ngp_stamp_cap = 0;
-__device__ int ngp_stamp_j = -1;
-#endif
 
 template <bool MIXED>
 __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkPtrs p, int Bc,

@@ -25,7 +25,32 @@ from nowcastautogp_amd.synthetic import bench_items
 WORDS = 32
 
 
+def analyse_thin(a, j):
+    """thin step of block column j (selected by passing -j): one row tile per wave"""
+    t = a[:, 2:9].astype(np.int64)
+    t0 = t[:, 0].min()
+    t = (t - t0) * 0.01
+    tc = ((a[:, 12:24].astype(np.int64) - t0) * 0.01).reshape(-1, 4, 3)
+    ok = a[:, 12] != 0
+    print(f"thin j={j}: {len(a)} wave records, launch span {t[:, 6].max():.0f} us")
+    def med(x):
+        return f"median {np.median(x):6.2f}  p10 {np.percentile(x, 10):6.2f}  p90 {np.percentile(x, 90):6.2f} us"
+    print("   start -> LDS-DMA + operand stages landed:", med(t[:, 1] - t[:, 0]))
+    print("   64-deep product                         :", med(t[:, 2] - t[:, 1]))
+    print("   barrier before the epilogue             :", med(t[:, 3] - t[:, 2]))
+    prev = t[ok, 3]
+    for it in range(4):
+        print(f"   pass {it}: K' arrived {np.median(tc[ok, it, 0] - prev):5.2f} | product + LDS "
+              f"{np.median(tc[ok, it, 1] - tc[ok, it, 0]):5.2f} | stores issued "
+              f"{np.median(tc[ok, it, 2] - tc[ok, it, 1]):5.2f}")
+        prev = tc[ok, it, 2]
+    print("   last pass -> stores retired             :", med(t[:, 6] - tc[:, 3, 2]))
+    print("   whole wave                              :", med(t[:, 6] - t[:, 0]))
+
+
 def analyse(a, j):
+    if j < 0:
+        return analyse_thin(a, -j)
     hw, ids = a[:, 0], a[:, 1]
     xcc = (hw >> 32) & 0xF
     h = hw & 0xFFFFFFFF
