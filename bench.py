@@ -491,7 +491,7 @@ def main():
             from oracle.cpu_baseline import usable_cores      # CPU-baseline leg only
             cores = usable_cores()[0]
             per_item_s = {"C5": 12.0}.get(args.config, 0.5)       # rough, to bound the sample
-            sample = args.cpu_sample or int(min(B, max(8, min(4 * cores, 20.0 * cores / per_item_s))))
+            sample = args.cpu_sample or int(min(B, max(8, min(64 * cores, 20.0 * cores / per_item_s))))
             idx = sorted(set(int(i) for i in np.linspace(0, B - 1, sample)))
             res["cpu_baseline"] = cpu_baseline(args.config, rank, args, idx,
                                                out["logml_full"].reshape(-1))
