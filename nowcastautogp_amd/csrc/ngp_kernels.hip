@@ -2166,7 +2166,7 @@ __global__ __launch_bounds__(256, 2) void aux_back_update_kernel(JobGeom g, Chun
 //   KA_REDUCED  reduced-program interpreter, one column per thread (kept apart from KA_DIRECT: the
 //               transcendental code of the direct interpreter cost it half its occupancy)
 //   KA_DIRECT   irregular times: direct evaluation of the full program
-enum { KA_SINGLE = 0, KA_REDUCED = 1, KA_DIRECT = 2 };
+enum { KA_SINGLE = 0, KA_REDUCED = 1, KA_DIRECT = 2, KA_CHAIN = 3 };
 // Workgroup = 64 CPT columns x 4 row quarters: wave w walks the w-th quarter of the rows for the
 // same columns and the four partial sums are added in wave order through LDS.  (One wave walking
 // all n0 rows was the critical path: a launch took as long as the item with the longest program.)
@@ -2188,8 +2188,11 @@ __global__ __launch_bounds__(256) void kapply_kernel(JobGeom g, ChunkPtrs p, con
     __syncthreads();
     constexpr bool SINGLE = MODE == KA_SINGLE;
     if constexpr (MODE != KA_DIRECT) {
-        const bool single = P.n_rops == 1 && P.rops[0] == OP_TABLE;   // workgroup-uniform
-        if (single != SINGLE) return;
+        // workgroup-uniform: which of the three lattice instantiations owns this item
+        const bool single = P.n_rops == 1 && P.rops[0] == OP_TABLE;
+        const bool chain = !single && P.rchain;
+        const int mine = single ? KA_SINGLE : (chain ? KA_CHAIN : KA_REDUCED);
+        if (mine != MODE) return;
     }
     const long ld = g.ld;
     const double *Ai = A + ((long)item * g.naux_pad + a0) * ld;
@@ -2230,6 +2233,67 @@ __global__ __launch_bounds__(256) void kapply_kernel(JobGeom g, ChunkPtrs p, con
         }
         __syncthreads();
         if (!on) continue;
+        if constexpr (MODE == KA_CHAIN) {
+            // chain programs (see fill_chain_kernel): 8 rows per decode, same formulas and order of
+            // operations per element as keval_reduced
+            static_assert(MODE != KA_CHAIN || CPT == 1, "the chain instantiation is one column per thread");
+            const int nops = P.n_rops;
+            for (int r8 = 0; r8 < NB; r8 += 8) {
+                double v[8];
+                for (int i = 0; i < nops; ++i) {
+                    const int code = __builtin_amdgcn_readfirstlane((int)P.rops[i]);
+                    const int op = code & 15;
+                    int lk = code >> 4, lf;
+                    if (i == 0) {
+                        lk = (op == OP_TABLE) ? RLEAF_TABLE : RLEAF_LINEAR;
+                        lf = __builtin_amdgcn_readfirstlane(
+                            (int)(op == OP_TABLE ? P.rslot[0] : P.rpoff[0]));
+                    } else {
+                        lf = __builtin_amdgcn_readfirstlane((int)P.rleaf[i]);
+                    }
+                    double b[8];
+                    if (lk == RLEAF_TABLE) {
+                        const double *tb = tab + (long)lf * g.R;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) b[k] = tb[abs(q1s[w][r8 + k] - q2[0])];
+                    } else {
+                        const double cc = P.params[lf], b0 = P.params[lf + 1], b1 = P.params[lf + 2];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            b[k] = b0 + b1 * (t1s[w][r8 + k] - cc) * (t2[0] - cc);
+                    }
+                    if (i == 0) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = b[k];
+                    } else if (op == NGP_OP_PLUS) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = v[k] + b[k];
+                    } else if (op == NGP_OP_TIMES) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = v[k] * b[k];
+                    } else {
+                        const int slot = __builtin_amdgcn_readfirstlane((int)P.rslot[i]);
+                        const double *sg = sig + (long)slot * g.npts;
+                        const double g2 = sg[col[0]];
+                        const bool fwd = op == NGP_OP_CHANGEPOINT;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const double g1 = sg[r0 + r8 + k];
+                            const double kl = fwd ? v[k] : b[k], kr = fwd ? b[k] : v[k];
+                            v[k] = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    double vv = v[k];
+                    if (r0 + r8 + k == col[0]) vv += diag;
+#pragma unroll
+                    for (int s = 0; s < NACC; ++s) acc[0][s] += As[w][s][r8 + k] * vv;
+                }
+            }
+            continue;
+        }
 #pragma unroll SINGLE ? 8 : 1
         for (int rr = 0; rr < NB; ++rr) {
             const int row = r0 + rr;
@@ -3236,6 +3300,8 @@ void launch_kapply(const JobGeom &g, const ChunkPtrs &p, const double *A, const 
                            sp);
         hipLaunchKernelGGL((kapply_kernel<NACC, 1, KA_REDUCED>), grid, dim3(256), 0, s, g, p, A, X,
                            R, sp);
+        hipLaunchKernelGGL((kapply_kernel<NACC, 1, KA_CHAIN>), grid, dim3(256), 0, s, g, p, A, X, R,
+                           sp);
     } else {
         hipLaunchKernelGGL((kapply_kernel<NACC, 1, KA_DIRECT>), grid, dim3(256), 0, s, g, p, A, X,
                            R, sp);
