@@ -347,7 +347,7 @@ extern "C" ngp_status ngp_ctx_create(int32_t device, ngp_ctx **out) {
         return NGP_ERR_NO_DEVICE;
     }
     size_t fr = 0, tot = 0;
-    if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->mem_cap = (size_t)(0.6 * (double)fr);
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->mem_cap = (size_t)(0.75 * (double)fr);
     else c->mem_cap = (size_t)8 << 30;
     *out = c;
     return NGP_OK;
@@ -832,7 +832,11 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
         if (mixed)
             item_bytes += l_bytes / 2 + 4 * nbt * g.nb0 + aux_bytes +
                           (refine ? sizeof(double) * NB * NB * (size_t)g.nb0 + 2 * aux_bytes : 0);
-        const int Bc = (int)std::min<size_t>((size_t)g.B, std::max<size_t>(1, c->mem_cap / item_bytes));
+        // as few chunks as the memory allows, of equal size (a short last chunk runs every launch
+        // of the sweep again for a fraction of the items)
+        const size_t bc_max = std::min<size_t>((size_t)g.B, std::max<size_t>(1, c->mem_cap / item_bytes));
+        const size_t nchunks = ((size_t)g.B + bc_max - 1) / bc_max;
+        const int Bc = (int)(((size_t)g.B + nchunks - 1) / nchunks);
         single_chunk = Bc >= g.B;
         // refinement sweeps need every block inverse M_j, not only the current one
         const size_t mstep = refine ? (size_t)Bc * NB * NB : 0;
