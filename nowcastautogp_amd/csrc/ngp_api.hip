@@ -491,6 +491,7 @@ inline Lane lane_of(ngp_ctx *c) { return Lane{c->stream, c->side, c->ev_fork, c-
 // sp != null and p0.L32 set: mixed-precision job (fat steps on chol_col_glds_kernel<MIXED>, class 9).
 // order_buf / order_prev ([bc] each, mixed jobs): every MIXED_REORDER block columns the items are
 // re-ranked by the fp64 tile products they needed since the last ranking.
+constexpr size_t MAX_CHUNK_ITEMS = 65535;   // gridDim.y
 constexpr int MIXED_REORDER = 16;
 void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int bc, EventTimer &tm,
                   size_t dinv_step = 0, const DevSpec *sp = nullptr, int32_t *order_buf = nullptr,
@@ -834,7 +835,9 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
                           (refine ? sizeof(double) * NB * NB * (size_t)g.nb0 + 2 * aux_bytes : 0);
         // as few chunks as the memory allows, of equal size (a short last chunk runs every launch
         // of the sweep again for a fraction of the items)
-        const size_t bc_max = std::min<size_t>((size_t)g.B, std::max<size_t>(1, c->mem_cap / item_bytes));
+        // (several kernels index the items of a chunk with blockIdx.y: at most 65,535 of them)
+        const size_t bc_max = std::min<size_t>(
+            std::min<size_t>((size_t)g.B, MAX_CHUNK_ITEMS), std::max<size_t>(1, c->mem_cap / item_bytes));
         const size_t nchunks = ((size_t)g.B + bc_max - 1) / bc_max;
         const int Bc = (int)(((size_t)g.B + nchunks - 1) / nchunks);
         single_chunk = Bc >= g.B;
@@ -1213,6 +1216,7 @@ extern "C" ngp_status ngp_factor_create(ngp_ctx *c, int32_t P, const ngp_kernel 
                                         ngp_factor **out) {
     if (!c || !out || !kernels || !t || !y || P <= 0 || n <= 0) return NGP_ERR_ARG;
     *out = nullptr;
+    if ((size_t)P > MAX_CHUNK_ITEMS) return NGP_ERR_TOO_LARGE;   // a resident factor is one chunk
     for (int i = 0; i < P; ++i) {
         ngp_status st = check_program(&kernels[i]);
         if (st) return st;
@@ -1342,8 +1346,10 @@ extern "C" ngp_status ngp_cov_batch(ngp_ctx *c, int32_t B, const ngp_kernel *ker
     if (e == hipSuccess) {
         EventTimer tm(c->profiling, s);
         tm.run(4, 0.0, 8.0 * (double)nout, [&] {
-            launch_cov((const DevProgram *)dp, B, (const double *)d1, n1, (const double *)d2, n2,
-                       add_diag, (double *)dout, dev_spec(c->spec), s);
+            for (int b0 = 0; b0 < B; b0 += (int)MAX_CHUNK_ITEMS)   // items are blockIdx.y
+                launch_cov((const DevProgram *)dp + b0, std::min(B - b0, (int)MAX_CHUNK_ITEMS),
+                           (const double *)d1, n1, (const double *)d2, n2, add_diag,
+                           (double *)dout + (size_t)b0 * n1 * n2, dev_spec(c->spec), s);
         });
         e = hipMemcpyAsync(out, dout, sizeof(double) * nout, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -1424,7 +1430,8 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
     const size_t item_bytes = l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 +
                               8 * (size_t)g.n0 + 8 * (size_t)ntri * GP;
-    int Bc = (int)std::min<size_t>((size_t)B, std::max<size_t>(1, c->mem_cap / item_bytes));
+    int Bc = (int)std::min<size_t>(std::min<size_t>((size_t)B, MAX_CHUNK_ITEMS),
+                                   std::max<size_t>(1, c->mem_cap / item_bytes));
     void *d_prog, *d_t, *d_y, *d_q = nullptr, *d_logdet, *d_info, *d_L, *d_dinv, *d_tab = nullptr,
          *d_sig = nullptr, *d_dtab = nullptr, *d_kinv, *d_alpha, *d_quad, *d_part, *d_grad, *d_logml;
     ngp_status st;

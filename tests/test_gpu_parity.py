@@ -404,6 +404,27 @@ def test_c2_full_workload(ctx):
         check("test_c2_full_workload:predictive", sg[b], rsg, TOL_PRED, cond, ctx=b)
 
 
+def test_more_items_than_one_grid_dimension_holds(ctx):
+    """Several kernels index the items of a chunk with blockIdx.y (at most 65,535): a batch of
+    70,000 short series must be cut into chunks for that reason alone (memory would take them all)
+    and come back complete — every item against the oracle on a sample, the rest against the
+    item they repeat."""
+    w = make_workload("C1", n=70, P=7, D=2, d=2, m=3)
+    B = 70_000
+    progs = [w.programs[i % 7] for i in range(B)]
+    lm, info = ctx.logml_batch(progs, w.t, w.y)
+    assert lm.shape == (B,) and not info.any()
+    for i in range(7):
+        ref, oi = oracle_np.logml(w.programs[i], w.t, w.y)
+        assert oi == 0
+        assert np.all(lm[i::7] == lm[i])                 # same item, same schedule: same bits
+        assert nerr(lm[i], ref) < 1e-10
+    g_lm, grads, g_info = ctx.logml_grad_batch(progs[:66_000], w.t, w.y)
+    assert not g_info.any() and nerr(g_lm, lm[:66_000]) < 1e-10
+    for i in range(7):
+        assert all(np.array_equal(grads[i], grads[k]) for k in range(i + 7, 66_000, 7 * 997))
+
+
 def test_headline_size_2048_gradient_and_resident_factor(ctx):
     """Headline length again, for the two paths the oracle is too slow to follow there: the
     gradient (checked as a directional derivative against central differences of the library's own
