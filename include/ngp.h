@@ -79,7 +79,9 @@ typedef struct ngp_spec {
      * / data rows is then refined against the fp64 covariance (G <- A X' + (X - A K) A',
      * A += (X - A K) (L L')^-1) until the predicted remaining relative error is below
      * refine_tol or refine_max steps were taken; an item that does not get there is
-     * reported with info = NGP_INFO_NOT_REFINED.  log det comes from the factor itself.   */
+     * reported with info = NGP_INFO_NOT_REFINED.  log det comes from the factor itself.
+     * Series of fewer than 128 or more than 8,319 points, gradient jobs and resident
+     * factors run in fp64 whatever this field says (ngp_job_mixed_stats: frac_f32 = 0).  */
     double  mixed_tau;     /* default 1e-6                                              */
     double  refine_tol;    /* default 1e-9                                              */
     int32_t refine_max;    /* default 3 (0: no refinement)                              */

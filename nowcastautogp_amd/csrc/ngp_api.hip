@@ -803,8 +803,11 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     EventTimer tm(c->profiling, s);
     HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)g.B, s));
     HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
-    // mixed precision needs at least one fat step (two block columns); shorter series run fp64
-    const bool mixed = j->spec.precision == NGP_PREC_MIXED && g.nb0 >= 2 && !g.aux_identity;
+    // mixed precision needs at least one fat step (two block columns); shorter series run fp64, and
+    // so do series of more than 129 block columns (n > 8,319): a fat step classifies its k-tiles
+    // in two 64-bit masks
+    const bool mixed = j->spec.precision == NGP_PREC_MIXED && g.nb0 >= 2 && g.nb0 <= 129 &&
+                       !g.aux_identity;
     const bool refine = mixed && j->spec.refine_max > 0;
     j->refine_steps.assign((size_t)g.B, 0);
     j->refine_delta.assign((size_t)g.B, 0.0);

@@ -137,3 +137,16 @@ def test_c5_full_size(ctx):
             assert nerr(got["logml_full"][b, 0], lm) < TOL_MIXED, (where, b)
             assert nerr(got["mu"][b, 0], mu) < TOL_MIXED, (where, b)
             assert nerr(np.diag(got["sigma"][b]), np.diag(sg)) < TOL_MIXED, (where, b)
+
+
+def test_series_too_long_for_the_tile_masks_run_in_fp64(ctx):
+    """A fat step classifies at most 128 k-tiles (two 64-bit masks): beyond 129 block columns
+    (n > 8,319) an NGP_PREC_MIXED job must run the fp64 schedule — same numbers as an fp64 job,
+    no fp32 tile products, no refinement — instead of dropping k-tiles."""
+    w = make_workload("C5", n=8400, P=2)
+    mix = _run(ctx, default_spec(NGP_PREC_MIXED), w.programs, w.t, w.y, w.t_new)
+    ref = _run(ctx, default_spec(), w.programs, w.t, w.y, w.t_new)
+    assert not mix["info"].any() and not ref["info"].any()
+    assert (mix["frac_f32"] == 0).all() and (mix["refine_steps"] == 0).all()
+    assert np.array_equal(mix["logml_full"], ref["logml_full"])
+    assert np.array_equal(mix["mu"], ref["mu"]) and np.array_equal(mix["sigma"], ref["sigma"])
