@@ -57,6 +57,10 @@ enum {
 #define NGP_MAX_PARAMS 96  /* continuous parameters per kernel tree            */
 #define NGP_MAX_STACK  16  /* RPN evaluation stack depth                       */
 #define NGP_MAX_AUX    192 /* appended + forecast rows per item (d_tail+d+m+1) */
+/* Size limits beyond these (NGP_ERR_TOO_LARGE): a series of more than 16,256 points (11,520 for
+ * ngp_logml_grad_batch) — an item's factor storage is addressed with 32-bit byte offsets; a
+ * resident factor of more than 65,535 particles.  Batches of any size are cut into chunks that
+ * fit the device memory; series longer than 8,319 points run NGP_PREC_MIXED jobs in fp64.        */
 
 /* Formula variants.  AutoGP.jl's source is not available in the build
  * container, so the per-node formulas are restated from memory (SURVEY.md

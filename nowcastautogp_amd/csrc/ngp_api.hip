@@ -225,6 +225,9 @@ bool detect_lattice(const std::vector<double> &t, double *h_out, std::vector<int
     if (g <= 0.0) return false;
     const double qmaxd = std::round(span / g);
     if (qmaxd < 1.0 || qmaxd > (double)(1 << 20)) return false;
+    // a lattice far sparser than the data (a few points on a very fine grid) would cost more in
+    // tables (R entries per stationary subtree and item) than direct evaluation costs in the fill
+    if (qmaxd > 16.0 * (double)n + 4096.0) return false;
     const double h = span / qmaxd;
     const double scale = std::max(std::max(std::fabs(tmin), std::fabs(tmax)), 1.0);
     q->resize(n);
@@ -492,6 +495,9 @@ inline Lane lane_of(ngp_ctx *c) { return Lane{c->stream, c->side, c->ev_fork, c-
 // order_buf / order_prev ([bc] each, mixed jobs): every MIXED_REORDER block columns the items are
 // re-ranked by the fp64 tile products they needed since the last ranking.
 constexpr size_t MAX_CHUNK_ITEMS = 65535;   // gridDim.y
+// The column kernels address an item's factor storage through a buffer descriptor with 32-bit
+// byte offsets: it must stay below 2 GiB (n <= 16,256 for value jobs, 11,520 for gradient jobs).
+inline bool item_too_large(int64_t item_stride) { return item_stride * 8 > (int64_t)0x7fffffff; }
 constexpr int MIXED_REORDER = 16;
 void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int bc, EventTimer &tm,
                   size_t dinv_step = 0, const DevSpec *sp = nullptr, int32_t *order_buf = nullptr,
@@ -600,6 +606,7 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     g.y_shared = (ldy == 0) ? 1 : 0;
     g.ld = g.n0;
     g.item_stride = (int64_t)(g.n0 + g.naux_pad) * g.n0;
+    if (item_too_large(g.item_stride)) return NGP_ERR_TOO_LARGE;
     g.npts = g.n0 + g.da + m;
     g.n_real = g.n0;
     g.aux_identity = 0;
@@ -1250,6 +1257,10 @@ extern "C" ngp_status ngp_factor_create(ngp_ctx *c, int32_t P, const ngp_kernel 
     f->n0 = (n / NB) * NB;
     f->nb0 = f->n0 / NB;
     f->item_stride = (int64_t)(f->n0 + NGP_MAX_AUX) * f->n0;
+    if (item_too_large(f->item_stride)) {
+        delete f;
+        return NGP_ERR_TOO_LARGE;
+    }
     ngp_status st = NGP_OK;
     {
         std::lock_guard<std::mutex> lk(c->mu);
@@ -1393,6 +1404,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     g.y_shared = (ldy == 0) ? 1 : 0;
     g.ld = g.n0;
     g.item_stride = (int64_t)(g.n0 + g.naux_pad) * g.n0;
+    if (item_too_large(g.item_stride)) return NGP_ERR_TOO_LARGE;
     g.npts = g.n0;
     g.maxstat = std::max(maxstat, 1);
     g.maxcp = std::max(maxcp, 1);

@@ -404,6 +404,20 @@ def test_c2_full_workload(ctx):
         check("test_c2_full_workload:predictive", sg[b], rsg, TOL_PRED, cond, ctx=b)
 
 
+def test_series_beyond_the_addressable_size_are_refused_not_mangled(ctx):
+    """The column kernels address an item's factor storage with 32-bit byte offsets (2 GiB): longer
+    series must come back as NGP_ERR_TOO_LARGE from staging, before anything is allocated."""
+    from nowcastautogp_amd._lib import NgpError
+    prog = make_workload("C1", n=70, P=1).programs[0]
+    for n, call in ((16_400, lambda t, y: ctx.stage_logml([prog], t, y)),
+                    (11_700, lambda t, y: ctx.logml_grad_batch([prog], t, y)),
+                    (16_400, lambda t, y: ctx.factor([prog], t, y))):
+        t = np.arange(n) / (n - 1.0)
+        with pytest.raises(NgpError) as ei:
+            call(t, np.sin(9.0 * t))
+        assert ei.value.status == -3, ei.value
+
+
 def test_more_items_than_one_grid_dimension_holds(ctx):
     """Several kernels index the items of a chunk with blockIdx.y (at most 65,535): a batch of
     70,000 short series must be cut into chunks for that reason alone (memory would take them all)
