@@ -569,6 +569,39 @@ def test_maximum_aux_rows_and_largest_program(ctx):
                           rng.standard_normal((1, d + 1)), t_more[n + d + 1:])
 
 
+def test_three_aux_tiles_through_the_column_sweep(ctx):
+    """192 aux rows (three 64-row tiles) beside nine block columns: the fat and thin steps carry
+    several aux tiles per item, and the scenario algebra works on the full 192 x 192 Gram."""
+    rng = np.random.Generator(np.random.PCG64(18))
+    n, d, m = 63 + 64 * 9, 60, 68
+    t_all = np.arange(n + d + m) / (n - 1)
+    y = np.sin(11.0 * t_all[:n]) + 0.2 * rng.standard_normal(n)
+    y_add = 0.3 * rng.standard_normal((3, d))
+    progs = [gp.to_program(gp.Plus(gp.Times(gp.Linear(0.3, 0.2, 0.8), gp.Periodic(0.9, 0.11, 0.7)),
+                                   gp.GammaExponential(0.15, 1.4, 0.5))) + (0.04,),
+             gp.to_program(gp.ChangePoint(gp.SquaredExponential(0.2, 0.9), gp.Periodic(0.7, 0.2, 0.6),
+                                          0.6, 0.08)) + (0.03,)]
+    out = ctx.nowcast_batch(progs, t_all[:n], y, t_all[n:n + d], y_add, t_all[n + d:])
+    assert not out["info"].any()
+    for b, prog in enumerate(progs):
+        lb, lf, mu, sg, info = oracle_np.nowcast(prog, t_all[:n], y, t_all[n:n + d], y_add,
+                                                 t_all[n + d:])
+        assert info == 0
+        cond = np.linalg.cond(oracle_np.cov(prog, t_all[:n + d], t_all[:n + d], True))
+        check("test_three_aux_tiles:logml", out["logml_full"][b], lf, TOL_LOGML, cond)
+        check("test_three_aux_tiles:logml", out["logml_base"][b], lb, TOL_LOGML, cond)
+        check("test_three_aux_tiles:predictive", out["mu"][b], mu, TOL_PRED, cond)
+        check("test_three_aux_tiles:predictive", out["sigma"][b], sg, TOL_PRED, cond)
+    # the same through the resident factor
+    fac = ctx.factor(progs, t_all[:n], y)
+    try:
+        got = fac.nowcast(t_all[n:n + d], y_add, t_all[n + d:], True)
+    finally:
+        fac.close()
+    assert nerr(got["logml_full"], out["logml_full"]) < 1e-10
+    assert nerr(got["mu"], out["mu"]) < 1e-8 and nerr(got["sigma"], out["sigma"]) < 1e-8
+
+
 def test_limits_are_refused(ctx):
     # 65 ops > NGP_MAX_OPS
     big = ([2] * 33 + [6] * 32, [0.1] * 99, 0.1)
