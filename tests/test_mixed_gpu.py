@@ -150,3 +150,24 @@ def test_series_too_long_for_the_tile_masks_run_in_fp64(ctx):
     assert (mix["frac_f32"] == 0).all() and (mix["refine_steps"] == 0).all()
     assert np.array_equal(mix["logml_full"], ref["logml_full"])
     assert np.array_equal(mix["mu"], ref["mu"]) and np.array_equal(mix["sigma"], ref["sigma"])
+
+
+def test_mixed_with_three_aux_tiles(ctx):
+    """192 aux rows (appended + forecast + data) under NGP_PREC_MIXED: the refinement's sweeps and
+    its 192 x 192 Gram products against the fp64 path."""
+    rng = np.random.Generator(np.random.PCG64(4))
+    w = make_workload("C5", n=63 + 64 * 11, P=6)
+    n, d, m = w.n, 60, 68
+    step = w.t[1] - w.t[0]
+    t_add = w.t[-1] + step * np.arange(1, d + 1)
+    t_new = t_add[-1] + step * np.arange(1, m + 1)
+    tt = np.concatenate([w.t, t_add])
+    yy = np.concatenate([w.y, w.y[-1] + 0.05 * rng.standard_normal(d)])
+    ref64 = _run(ctx, default_spec(), w.programs, tt, yy, t_new)
+    mix = _run(ctx, default_spec(NGP_PREC_MIXED), w.programs, tt, yy, t_new)
+    assert not ref64["info"].any() and not mix["info"].any(), (ref64["info"], mix["info"])
+    assert (mix["refine_steps"] >= 1).all()
+    for b in range(len(w.programs)):
+        assert nerr(mix["logml_full"][b], ref64["logml_full"][b]) < TOL_MIXED
+        assert nerr(mix["mu"][b], ref64["mu"][b]) < TOL_MIXED
+        assert nerr(np.diag(mix["sigma"][b]), np.diag(ref64["sigma"][b])) < TOL_MIXED
