@@ -171,3 +171,21 @@ def test_mixed_with_three_aux_tiles(ctx):
         assert nerr(mix["logml_full"][b], ref64["logml_full"][b]) < TOL_MIXED
         assert nerr(mix["mu"][b], ref64["mu"][b]) < TOL_MIXED
         assert nerr(np.diag(mix["sigma"][b]), np.diag(ref64["sigma"][b])) < TOL_MIXED
+
+
+def test_mixed_on_irregular_times(ctx):
+    """Times off any lattice: the covariance re-evaluation of the refinement goes through the
+    direct interpreter (no tables)."""
+    rng = np.random.Generator(np.random.PCG64(6))
+    w = make_workload("C5", n=900, P=6)
+    t = np.sort(w.t + (w.t[1] - w.t[0]) * rng.uniform(-0.3, 0.3, w.t.size))
+    t_new = t[-1] + (w.t[1] - w.t[0]) * np.array([1.1, 2.3, 3.2, 7.9])
+    ref64 = _run(ctx, default_spec(), w.programs, t, w.y, t_new)
+    mix = _run(ctx, default_spec(NGP_PREC_MIXED), w.programs, t, w.y, t_new)
+    assert not ref64["info"].any() and not mix["info"].any(), (ref64["info"], mix["info"])
+    for b in range(len(w.programs)):
+        assert nerr(mix["logml_full"][b], ref64["logml_full"][b]) < TOL_MIXED
+        assert nerr(mix["mu"][b], ref64["mu"][b]) < TOL_MIXED
+        assert nerr(np.diag(mix["sigma"][b]), np.diag(ref64["sigma"][b])) < TOL_MIXED
+    mu, sg, lm, info = oracle_np.predict(w.programs[2], t, w.y, t_new)
+    assert info == 0 and nerr(mix["logml_full"][2, 0], lm) < TOL_MIXED and nerr(mix["mu"][2, 0], mu) < TOL_MIXED
