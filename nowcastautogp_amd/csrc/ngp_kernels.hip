@@ -721,6 +721,23 @@ __global__ __launch_bounds__(256) void fill_chain_kernel(JobGeom g, ChunkPtrs p,
     }
 }
 
+#ifdef NGP_PHASE_STAMPS
+// Diagnostic build only (scripts/fat_phases.py; never defined for libngp.so): every wave of the
+// fat step whose block column is ngp_stamp_j leaves 100-MHz timestamps of its phases and the CU /
+// SIMD it ran on.
+constexpr int STAMP_WORDS = 32;
+__device__ unsigned long long *ngp_stamps = nullptr;
+__device__ unsigned int ngp_stamp_count = 0, ngp_stamp_cap = 0;
+__device__ int ngp_stamp_j = -1;
+#endif
+#ifdef NGP_PHASE_STAMPS
+#define NGP_STAMP(var) var = __builtin_amdgcn_s_memrealtime()
+// anchored: not before `dep` is computed, ordered with the memory operations around it
+#define NGP_STAMP_DEP(var, dep) \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) : "v"(dep) : "memory")
+#else
+#define NGP_STAMP(var)
+#endif
 // ---------------------------------------------------------------------------------------
 // chol_diag: factor the 64x64 diagonal block of block column j
 // ---------------------------------------------------------------------------------------
@@ -762,6 +779,10 @@ __global__ __launch_bounds__(256, 4) void chol_diag_kernel(JobGeom g, ChunkPtrs 
     const int kmax = j * NB;
     const int r16 = lane & 15, q = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
+#ifdef NGP_PHASE_STAMPS
+    unsigned long long td[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    NGP_STAMP_DEP(td[0], lane);
+#endif
 
     if (tid == 0) bad = 0;
 
@@ -825,6 +846,9 @@ __global__ __launch_bounds__(256, 4) void chol_diag_kernel(JobGeom g, ChunkPtrs 
                 }
     }
     __syncthreads();
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(td[1], lane);
+#endif
 
     // ---- right-looking Cholesky of the 64x64 tile, register-blocked: thread (bi, bj) owns the 4x4
     //      block rows 4bi.., cols 4bj...  Four pivots are retired per round (16 rounds, two barriers
@@ -932,6 +956,9 @@ __global__ __launch_bounds__(256, 4) void chol_diag_kernel(JobGeom g, ChunkPtrs 
         }
     }
     __syncthreads();
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(td[2], lane);
+#endif
     if (tid < NB) logs[tid] = log(Lt[tri(tid, tid)]);
 
     // ---- M = L_jj^-1 (64 x 64, lower): the four 16x16 diagonal-block inverses by forward
@@ -958,6 +985,9 @@ __global__ __launch_bounds__(256, 4) void chol_diag_kernel(JobGeom g, ChunkPtrs 
             if (i >= c) Mt[tri(TB * b + i, TB * b + c)] = x[i];
     }
     __syncthreads();
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(td[3], lane);
+#endif
     {
         const int ra = tid >> 4, cb = tid & 15;
         for (int dist = 1; dist < NB / TB; ++dist)
@@ -983,6 +1013,9 @@ __global__ __launch_bounds__(256, 4) void chol_diag_kernel(JobGeom g, ChunkPtrs 
                 __syncthreads();
             }
     }
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(td[4], lane);
+#endif
     // strip order: strip (cb4, jt) is the A operand of v_mfma_f64_4x4x4 for output rows
     // 4 cb4 .. 4 cb4 + 3 against the 16 columns of tile jt: lane l holds
     // M[4 cb4 + (l & 3)][16 jt + 4 ((l >> 2) & 3) + (l >> 4)] — one coalesced 512-B load per strip
@@ -1001,6 +1034,18 @@ __global__ __launch_bounds__(256, 4) void chol_diag_kernel(JobGeom g, ChunkPtrs 
         p.logdet[item] += s;
         if (bad && p.info[item] == 0) p.info[item] = kmax + bad;
     }
+#ifdef NGP_PHASE_STAMPS
+    NGP_STAMP_DEP(td[5], lane);
+    if (j == ngp_stamp_j - 1000 && tid == 0) {     // selected by passing 1000 + j to fat_phases.py
+        const unsigned idx = atomicAdd(&ngp_stamp_count, 1u);
+        if (idx < ngp_stamp_cap) {
+            unsigned long long *o = ngp_stamps + (size_t)idx * STAMP_WORDS;
+            o[0] = 0; o[1] = (unsigned long long)item;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[2 + i] = td[i];
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1085,23 +1130,6 @@ __device__ __forceinline__ void gemm_rows(double (&acc)[NA][4][4], const double 
 // order, written to a per-wave LDS tile and from there to HBM as full 512-byte rows.
 // LDS: M strips (32 KiB, shared) + 16 tile rows x 64 columns per wave and pass, pitch 66 doubles.
 // ---------------------------------------------------------------------------------------
-#ifdef NGP_PHASE_STAMPS
-// Diagnostic build only (scripts/fat_phases.py; never defined for libngp.so): every wave of the
-// fat step whose block column is ngp_stamp_j leaves 100-MHz timestamps of its phases and the CU /
-// SIMD it ran on.
-constexpr int STAMP_WORDS = 32;
-__device__ unsigned long long *ngp_stamps = nullptr;
-__device__ unsigned int ngp_stamp_count = 0, ngp_stamp_cap = 0;
-__device__ int ngp_stamp_j = -1;
-#endif
-#ifdef NGP_PHASE_STAMPS
-#define NGP_STAMP(var) var = __builtin_amdgcn_s_memrealtime()
-// anchored: not before `dep` is computed, ordered with the memory operations around it
-#define NGP_STAMP_DEP(var, dep) \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) : "v"(dep) : "memory")
-#else
-#define NGP_STAMP(var)
-#endif
 constexpr int EPI_PITCH = 66;                       // doubles per LDS row (16-byte aligned rows)
 constexpr int EPI_M_BYTES = NB * NB * 8;            // M strips, shared by the workgroup's tiles
 constexpr int EPI_WAVE_BYTES = 16 * EPI_PITCH * 8;  // 16 tile rows x 64 columns per wave and pass

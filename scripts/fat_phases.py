@@ -48,7 +48,21 @@ def analyse_thin(a, j):
     print("   whole wave                              :", med(t[:, 6] - t[:, 0]))
 
 
+def analyse_diag(a, j):
+    """chol_diag of block column j (selected by passing 1000 + j): one workgroup per item"""
+    t = (a[:, 2:8].astype(np.int64) - int(a[:, 2].min())) * 0.01
+    names = ["C_jj = K_jj - L_j L_j' (pending k) -> LDS", "64 x 64 Cholesky (16 rounds)",
+             "store L, diagonal-block inverses", "block recursion for M = L^-1", "M strips, logdet"]
+    print(f"chol_diag j={j}: {len(a)} workgroups")
+    for k, nm in enumerate(names):
+        d = t[:, k + 1] - t[:, k]
+        print(f"   {nm:>44s}: median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f} us")
+    print(f"   {'whole workgroup':>44s}: median {np.median(t[:, 5] - t[:, 0]):6.2f} us")
+
+
 def analyse(a, j):
+    if j >= 1000:
+        return analyse_diag(a, j - 1000)
     if j < 0:
         return analyse_thin(a, -j)
     hw, ids = a[:, 0], a[:, 1]
@@ -133,7 +147,8 @@ def main():
     P = int(sys.argv[2]) if len(sys.argv) > 2 else 16
     lib = C.CDLL(os.environ["NGP_LIB"])
     ctx = _lib.Context(0)
-    w, progs, Y, tt = bench_items("C3", 0, None, P, None)
+    scen = int(sys.argv[3]) if len(sys.argv) > 3 else None
+    w, progs, Y, tt = bench_items("C3", 0, None, P, scen)
     job = ctx.stage_predict(progs, tt, Y, w.t_new)
     job.run()                                   # warm
     cap = len(progs) * 20 * 4
