@@ -573,18 +573,48 @@ def _advance_weights(logw, lm_new, lm_old):
     return np.where(np.isnan(out), -np.inf, out)
 
 
-def check_horizon(n_obs: int, d: int, m: int) -> None:
+def horizon_blocks(n_obs: int, d: int, m: int):
     """The library carries the appended and forecast points of a query as at most NGP_MAX_AUX
     rows beside the factor: (n mod 64) + d + m + 1 <= NGP_MAX_AUX (include/ngp.h).  The reference
-    has no such limit; say so clearly instead of surfacing 'problem exceeds a library limit'."""
+    has no such limit, so longer horizons are served in several calls: returns None when the m
+    dates fit one call, else the (lo, hi) blocks to query PAIRWISE (``predict_in_blocks``) — each
+    block is at most half the room of a call, so any two of them fit together and every
+    cross-covariance block of the joint predictive comes out of some call."""
     from ._abi import NGP_MAX_AUX
     room = NGP_MAX_AUX - (n_obs % 64) - d - 1
-    if m > room:
+    if m <= room:
+        return None
+    blk = room // 2
+    if blk < 1:
         raise ValueError(
-            f"forecast horizon of {m} dates is too long for one call: with {n_obs} observations"
-            + (f" and {d} appended points" if d else "")
-            + f" at most {max(room, 0)} forecast dates fit (NGP_MAX_AUX = {NGP_MAX_AUX} rows beside "
-            "the factor; split the dates over several calls)")
+            f"forecast horizon: with {n_obs} observations and {d} appended points no forecast "
+            f"dates fit beside the factor (NGP_MAX_AUX = {NGP_MAX_AUX} rows); append fewer points "
+            "per call")
+    return [(lo, min(lo + blk, m)) for lo in range(0, m, blk)]
+
+
+def predict_in_blocks(call, t_new: np.ndarray, blocks):
+    """``call(t_sub) -> (mu [..., m_sub], sigma [P, m_sub, m_sub], info [P], extra)`` for any
+    subset of the dates.  Queries every pair of blocks once and assembles the joint mean
+    [..., m] and covariance [P, m, m]; ``extra`` (whatever does not depend on the dates) is the
+    first call's.  The blocks of a pair are conditionally dependent given the data, which is why
+    single-block calls would not do: Sigma[a, b] only exists inside a call that holds both."""
+    m = t_new.size
+    q = len(blocks)
+    pairs = [(a, b) for a in range(q) for b in range(a + 1, q)] or [(0, 0)]
+    mu = sigma = info = extra = None
+    for a, b in pairs:
+        idx = np.arange(*blocks[a]) if a == b else np.concatenate(
+            [np.arange(*blocks[a]), np.arange(*blocks[b])])
+        mu_s, sg_s, info_s, extra_s = call(t_new[idx])
+        if mu is None:
+            mu = np.empty(mu_s.shape[:-1] + (m,))
+            sigma = np.empty((sg_s.shape[0], m, m))
+            info, extra = np.array(info_s, copy=True), extra_s
+        mu[..., idx] = mu_s
+        sigma[:, idx[:, None], idx[None, :]] = sg_s
+        info = np.where(info != 0, info, info_s)
+    return mu, sigma, info, extra
 
 
 def add_data(model: GPModel, ds, y) -> None:
@@ -650,12 +680,20 @@ class MixtureMVN:
 def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
     t, y = model._obs()
     t_new = model.ds_transform.apply(to_days(list(ds)))
-    check_horizon(t.size, 0, t_new.size)
     fac = model._factor()
-    if fac is not None:
-        mu, sigma, _, info = fac.predict(t_new, noise_on_new)
-    else:
-        mu, sigma, _, info = model._eng().predict(model.programs(), t, y, t_new, noise_on_new)
+
+    def call(ts):
+        if fac is not None:
+            mu_s, sg_s, _, info_s = fac.predict(ts, noise_on_new)
+        else:
+            mu_s, sg_s, _, info_s = model._eng().predict(model.programs(), t, y, ts, noise_on_new)
+        return mu_s, sg_s, info_s, None
+
+    blocks = horizon_blocks(t.size, 0, t_new.size)
+    if blocks is None:
+        mu, sigma, info, _ = call(t_new)
+    else:       # longer than one call carries: pairwise calls, joint covariance assembled
+        mu, sigma, info, _ = predict_in_blocks(call, t_new, blocks)
     bad = np.flatnonzero(info)
     if bad.size:
         raise PosDefException(int(info[bad[0]]), int(bad[0]))
@@ -669,6 +707,8 @@ def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
         covs = distributed.all_gather_rows(covs.reshape(covs.shape[0], -1), sizes=sizes).reshape(
             (-1,) + covs.shape[1:])
         w = distributed.all_gather_rows(w[:, None], sizes=sizes)[:, 0]
-    # shared stream: the same draws on every rank
-    return MixtureMVN(means, covs, w, model.rng_shared,
-                      getattr(model._eng(), "mixture_sample", None))
+    # shared stream: the same draws on every rank; the device sampler takes at most NGP_MAX_AUX
+    # dates, longer horizons are drawn on the host
+    from ._abi import NGP_MAX_AUX
+    sampler = getattr(model._eng(), "mixture_sample", None) if t_new.size <= NGP_MAX_AUX else None
+    return MixtureMVN(means, covs, w, model.rng_shared, sampler)

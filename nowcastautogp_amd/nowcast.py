@@ -179,12 +179,21 @@ def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transform
     y_add = np.stack([model.y_transform.apply(np.asarray(nc.y, dtype=np.float64))
                       for nc in nowcasts])
     t_new = model.ds_transform.apply(autogp.to_days(dates))
-    autogp.check_horizon(t.size, t_add.size, t_new.size)
     fac = model._factor()
-    if fac is not None:
-        out = fac.nowcast(t_add, y_add, t_new, True)
-    else:
-        out = model._eng().nowcast(model.programs(), t, y, t_add, y_add, t_new, True)
+
+    def call(ts):
+        if fac is not None:
+            o = fac.nowcast(t_add, y_add, ts, True)
+        else:
+            o = model._eng().nowcast(model.programs(), t, y, t_add, y_add, ts, True)
+        return o["mu"], o["sigma"], o["info"], o
+
+    blocks = autogp.horizon_blocks(t.size, t_add.size, t_new.size)
+    if blocks is None:
+        out = call(t_new)[3]
+    else:       # a horizon longer than one call carries: pairwise calls (autogp.predict_in_blocks)
+        mu_all, sg_all, info_all, first = autogp.predict_in_blocks(call, t_new, blocks)
+        out = dict(first, mu=mu_all, sigma=sg_all, info=info_all)
     bad = np.flatnonzero(out["info"])
     if bad.size:
         raise autogp.PosDefException(int(out["info"][bad[0]]), int(bad[0]))
@@ -194,7 +203,8 @@ def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transform
     rng = model.rng_shared
     D = len(nowcasts)
     sampler = getattr(model._eng(), "mixture_sample", None)
-    if sampler is not None and len(dates) > 0:
+    from ._abi import NGP_MAX_AUX
+    if sampler is not None and 0 < len(dates) <= NGP_MAX_AUX:   # the device sampler's limit
         # every scenario at once: add_data! weight update, maybe_resample! (ancestors ~ w, weights
         # -> ancestor counts / P), then ONE device call that draws from all D mixtures
         logw = model.log_weights[None, :] + (out["logml_full"].T - out["logml_base"][None, :])

@@ -197,8 +197,30 @@ def test_an_engine_that_fails_twice_leaves_finite_weights():
     assert np.isfinite(w).all() and w[0] == 0.0 and np.isfinite(ess)
 
 
-def test_too_long_a_horizon_is_a_clear_error(eng):
-    model = mc.fitted(eng, seed=22)
+def test_a_horizon_longer_than_one_call_is_served_in_pairs_of_blocks(eng):
+    """The library carries at most NGP_MAX_AUX rows beside a factor; the reference has no horizon
+    limit.  400 dates after 20 observations: blocks of 85, every pair queried once, the joint mean
+    and covariance assembled — identical to what one (unlimited) oracle call gives."""
+    model = mc.fitted(eng, seed=22, n_particles=2)
+    dates = mc.days(20, 20 + 400)
+    assert autogp.horizon_blocks(20, 0, 150) is None and len(autogp.horizon_blocks(20, 0, 400)) == 5
+    mix = autogp.predict_mvn(model, dates)
+    t, y = model._obs()
+    t_new = model.ds_transform.apply(autogp.to_days(dates))
+    mu, sigma, _, info = eng.predict(model.programs(), t, y, t_new, True)
+    assert not info.any()
+    s = model.y_transform.slope
+    assert np.allclose(mix.means, (mu - model.y_transform.intercept) / s, rtol=1e-9, atol=1e-9)
+    assert np.allclose(mix.covs, sigma / (s * s), rtol=1e-9, atol=1e-12)
+    assert mix.sampler is None                       # more dates than the device sampler takes
+    draws = mix.rand(7)
+    assert draws.shape == (400, 7) and np.isfinite(draws).all()
+    # the batched nowcast path: 3 appended points, 400 dates
+    ident = lambda v: v  # noqa: E731
+    scen = [nc.TData(mc.days(20, 23), v, transformation=ident)
+            for v in ([110.0, 111.0, 112.0], [108.0, 113.0, 109.0])]
+    fc = nc.forecast_with_nowcasts(model, scen, mc.days(23, 23 + 400), 4)
+    assert fc.shape == (400, 8) and np.isfinite(fc).all()
+    # so many appended points that no date fits beside them: a clear error
     with pytest.raises(ValueError, match="forecast horizon"):
-        autogp.predict_mvn(model, mc.days(20, 20 + 400))
-    assert autogp.predict_mvn(model, mc.days(20, 20 + 150)).means.shape[1] == 150
+        autogp.horizon_blocks(20, 171, 5)

@@ -98,3 +98,30 @@ def test_repeated_forecasts_reuse_the_resident_factor(eng):
     autogp.mcmc_parameters(base, 1)
     autogp.predict_mvn(base, mc.days(12, 15))
     assert base._fcache.factor is not handle
+
+
+def test_a_horizon_longer_than_one_call(eng):
+    """300 forecast dates (the library carries at most 192 aux rows per call): the mirror queries the
+    blocks pairwise and assembles the joint predictive; means and covariances against one unlimited
+    oracle call, through the resident factor and through the one-shot path."""
+    import numpy as np
+    from nowcastautogp_amd import nowcast as nc
+    from tests.engine_oracle import OracleEngine
+
+    model = mc.fitted(eng, seed=5, n_particles=3)
+    dates = mc.days(20, 320)
+    mix = autogp.predict_mvn(model, dates)
+    t, y = model._obs()
+    t_new = model.ds_transform.apply(autogp.to_days(dates))
+    mu, sigma, _, info = OracleEngine().predict(model.programs(), t, y, t_new, True)
+    assert not info.any()
+    s = model.y_transform.slope
+    ref_m, ref_c = (mu - model.y_transform.intercept) / s, sigma / (s * s)
+    assert np.max(np.abs(mix.means - ref_m)) <= 1e-7 * np.max(np.abs(ref_m))
+    assert np.max(np.abs(mix.covs - ref_c)) <= 1e-7 * np.max(np.abs(ref_c))
+    fc = nc.forecast(model, dates, 6)
+    assert fc.shape == (300, 6) and np.isfinite(fc).all()
+    ident = lambda v: v  # noqa: E731
+    scen = [nc.TData(mc.days(20, 22), v, transformation=ident) for v in ([111.0, 112.0], [109.0, 113.0])]
+    fcn = nc.forecast_with_nowcasts(model, scen, mc.days(22, 322), 3)
+    assert fcn.shape == (300, 6) and np.isfinite(fcn).all()
