@@ -2004,7 +2004,31 @@ __global__ __launch_bounds__(64 * NW, 2) void diag_ahead_kernel(JobGeom g, Chunk
     // k-range in NW pieces, each a multiple of 16 (gemm_rows' stage depth)
     const int kmax = j * NB, per = ((kmax / 16 + NW - 1) / NW) * 16;
     const int k0 = min(wave * per, kmax), k1 = min(k0 + per, kmax);
-    gemm_rows<4>(acc4, pd, pd, ld, k0, k1);
+    // Self-product of the 64 rows: both 64-byte halves of a row's 128-byte line are requested
+    // together, one 16-deep stage ahead.  (gemm_rows asks for the halves one MFMA stage apart, and
+    // the PMC counters showed every line of these rows fetched from HBM twice: 1.85 x the
+    // algorithmic bytes, profiles/r02/README.md.)  Same MFMA order as gemm_rows: bit-identical.
+    if (k1 > k0) {
+        Frag8<4> f[2][2];
+        load_frag8(f[0][0], pd + k0, ld);
+        load_frag8(f[0][1], pd + k0 + 8, ld);
+        for (int kc = k0; kc < k1; kc += 32) {
+            if (kc + 16 < k1) {
+                load_frag8(f[1][0], pd + kc + 16, ld);
+                load_frag8(f[1][1], pd + kc + 24, ld);
+            }
+            mfma_frag8(acc4, f[0][0], f[0][0]);
+            mfma_frag8(acc4, f[0][1], f[0][1]);
+            if (kc + 16 < k1) {
+                if (kc + 32 < k1) {
+                    load_frag8(f[0][0], pd + kc + 32, ld);
+                    load_frag8(f[0][1], pd + kc + 40, ld);
+                }
+                mfma_frag8(acc4, f[1][0], f[1][0]);
+                mfma_frag8(acc4, f[1][1], f[1][1]);
+            }
+        }
+    }
     if constexpr (NW > 1) {
         for (int w = 1; w < NW; ++w) {          // wave w adds its tile; wave 0 collects last
             if (wave == w) {
