@@ -2705,6 +2705,123 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_kernel(JobGeom g, const doub
         }
 }
 
+// K^-1 = W W' for long series: a workgroup takes a 2 x 2 block of 64 x 64 tiles and stages the
+// four row tiles it needs (column tiles J0, J0+1 as the "panel", row tiles I0, I0+1) through LDS by
+// LDS-DMA, 16 columns at a time, exactly as the fat step of the factorisation does (same layout,
+// same swizzle, same mfma loop) — the wave-per-tile kernel above re-reads both row tiles of every
+// tile from HBM (24.6 GB per call at n = 2048 x 64 items, 5.5 TB/s: it was bound by that).  k
+// starts at 64 I0 for both row tiles; for I0 + 1 the first 64 columns are zeros of W (upper
+// triangular), which add nothing.  Within a 16-column chunk the MFMAs take k in ascending groups
+// of four (the fat step's order) where gemm_rows takes even then odd k of an 8-column stage: the
+// two kernels agree to rounding, not bit for bit.  Block pairs with bi >= bj; the tile above the
+// diagonal in a diagonal block is computed and dropped.
+__global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const double *L,
+                                                               double *Kinv, int nblk) {
+    constexpr int ROWB = 128, BLKB = 8 * ROWB + 128, STAGE = 32 * BLKB;
+    auto row_off = [](int row) { return (row >> 3) * BLKB + (row & 7) * ROWB; };
+    __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const int item = blockIdx.y;
+    const int pr = blockIdx.x;
+    if (pr >= nblk) return;
+    int bi = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= pr) ++bi;
+    while (bi * (bi + 1) / 2 > pr) --bi;
+    const int bj = pr - bi * (bi + 1) / 2;   // bi >= bj
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ltile = wave >> 1, col = wave & 1;
+    const int I0 = 2 * bi, J0 = 2 * bj;
+    const int I = I0 + ltile, J = J0 + col;
+    // a last, unpaired tile (odd nb0) is staged as a copy of its neighbour and not stored
+    const bool valid = I < g.nb0 && J < g.nb0 && I >= J;
+    const long ld = g.ld;
+    const double *Wb = L + (long)item * g.item_stride + (long)g.n0 * ld;
+    const int r16 = lane & 15, q = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(Wb), 0, (int)((long)g.n0 * ld * (long)sizeof(double)), 0x00020000);
+    // stage rows: waves 0,1 the panel (column tiles J0, J0+1), waves 2,3 the row tiles I0, I0+1
+    int src_tile = wave < 2 ? J0 + wave : I0 + (wave - 2);
+    if (src_tile >= g.nb0) src_tile = g.nb0 - 1;
+    const unsigned soff_base =
+        (unsigned)__builtin_amdgcn_readfirstlane((int)((long)src_tile * NB * ld * 8));
+    const unsigned row_step8 = (unsigned)(8 * ld * 8);
+    const unsigned voff_even = (unsigned)(((lane >> 3) * ld + 2 * ((lane & 7) ^ ((lane >> 4) & 7))) * 8);
+    const unsigned voff_odd = (unsigned)(((lane >> 3) * ld + 2 * ((lane & 7) ^ ((4 + (lane >> 4)) & 7))) * 8);
+    auto stage = [&](int buf, int k) {
+        const unsigned kb = (unsigned)k * 8u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            lds_ptr dst = (lds_ptr)(smem + buf * STAGE + (8 * wave + i) * BLKB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, (i & 1) ? voff_odd : voff_even,
+                                                     soff_base + i * row_step8 + kb, 0, 0);
+        }
+    };
+    unsigned a_addr[4], b_addr[4][4];
+    {
+        const int arow = 64 * col + r16;
+        const int akey = (r16 >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            a_addr[s] = (unsigned)(row_off(arow) + (((2 * s + (q >> 1)) ^ akey) << 4) + (q & 1) * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = (r16 + 4 * r) & 15;
+            const int brow = 128 + 64 * ltile + rr;
+            const int bkey = (rr >> 1) & 7;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                b_addr[r][s] =
+                    (unsigned)(row_off(brow) + (((2 * s + (q >> 1)) ^ bkey) << 4) + (q & 1) * 8);
+        }
+    }
+    double acc4[4][4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
+    const int kbeg = I0 * NB;
+    const int nchunks = (g.n0 - kbeg) / LDS_KC;
+    stage(0, kbeg);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
+        const char *buf = smem + cur * STAGE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            double a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 2 * BLKB);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                Rot4 br;
+                br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 2 * BLKB);
+                br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 2 * BLKB);
+                br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * 2 * BLKB);
+                br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * 2 * BLKB);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[jt], br);
+            }
+        }
+        __syncthreads();
+    }
+    if (!valid) return;
+    double *Ko = Kinv + (long)item * g.n0 * g.n0;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const f64x4 d = to_d16(acc4[jt][it]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                Ko[(long)(I * NB + 16 * it + r16) * g.n0 + J * NB + 16 * jt + q + 4 * s] = d[s];
+        }
+}
+
 // alpha[a] = sum_k W[a][k] z[k] (z = the data row of W), quad = z'z; one wave per row
 __global__ __launch_bounds__(256) void grad_alpha_kernel(JobGeom g, const double *L, double *alpha,
                                                          double *quad) {
@@ -3393,8 +3510,13 @@ void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipS
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
                       int Bc, hipStream_t s) {
     const int npairs = g.nb0 * (g.nb0 + 1) / 2;
-    hipLaunchKernelGGL(grad_kinv_kernel, dim3((npairs + 3) / 4, Bc), dim3(256), 0, s, g, L, Kinv,
-                       npairs);
+    if (g.nb0 >= 8) {   // long series: 2 x 2 tile blocks staged through LDS (HBM traffic halves)
+        const int nb2 = (g.nb0 + 1) / 2, nblk = nb2 * (nb2 + 1) / 2;
+        hipLaunchKernelGGL(grad_kinv_lds_kernel, dim3(nblk, Bc), dim3(256), 0, s, g, L, Kinv, nblk);
+    } else {
+        hipLaunchKernelGGL(grad_kinv_kernel, dim3((npairs + 3) / 4, Bc), dim3(256), 0, s, g, L, Kinv,
+                           npairs);
+    }
     hipLaunchKernelGGL(grad_alpha_kernel, dim3((g.n0 + 1 + 3) / 4, Bc), dim3(256), 0, s, g, L,
                        alpha, quad);
 }
