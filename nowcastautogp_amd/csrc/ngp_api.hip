@@ -428,8 +428,8 @@ struct ngp_job {
     ngp_spec spec{};
     // lattice jobs: items whose reduced program is a chain of more than one instruction / the other
     // items (ascending job-wide indices; device copies fill_chain_d / fill_other_d)
-    std::vector<int32_t> fill_chain, fill_other;
-    int32_t *fill_chain_d = nullptr, *fill_other_d = nullptr;
+    std::vector<int32_t> fill_chain, fill_other, fill_single;   // single: the whole tree is ONE table
+    int32_t *fill_chain_d = nullptr, *fill_other_d = nullptr, *fill_single_d = nullptr;
     // NGP_PREC_MIXED: per item, filled by ngp_job_run
     std::vector<int32_t> refine_steps;
     std::vector<double> refine_delta, frac32;
@@ -692,11 +692,15 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     if (g.lattice) CPY(j->qpts, h_q.data(), g.npts, int32_t);
     if (g.lattice && g.n0 > 0) {
         for (int i = 0; i < P; ++i)
-            (hp[(size_t)i].rchain && hp[(size_t)i].n_rops > 1 ? j->fill_chain : j->fill_other)
+            (hp[(size_t)i].n_rops == 1 && hp[(size_t)i].rops[0] == OP_TABLE
+                 ? j->fill_single
+                 : hp[(size_t)i].rchain ? j->fill_chain : j->fill_other)
                 .push_back(i);
         if ((st = job_alloc(j, &j->fill_chain_d, std::max<size_t>(j->fill_chain.size(), 1))) ||
-            (st = job_alloc(j, &j->fill_other_d, std::max<size_t>(j->fill_other.size(), 1))))
+            (st = job_alloc(j, &j->fill_other_d, std::max<size_t>(j->fill_other.size(), 1))) ||
+            (st = job_alloc(j, &j->fill_single_d, std::max<size_t>(j->fill_single.size(), 1))))
             return fail(st);
+        CPY(j->fill_single_d, j->fill_single.data(), j->fill_single.size(), int32_t);
         CPY(j->fill_chain_d, j->fill_chain.data(), j->fill_chain.size(), int32_t);
         CPY(j->fill_other_d, j->fill_other.data(), j->fill_other.size(), int32_t);
     }
@@ -901,6 +905,7 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
                 };
                 range(j->fill_chain, j->fill_chain_d, &p.fill_chain, &p.n_fill_chain);
                 range(j->fill_other, j->fill_other_d, &p.fill_other, &p.n_fill_other);
+                range(j->fill_single, j->fill_single_d, &p.fill_single, &p.n_fill_single);
                 p.fill_base = b0;
             }
             if (mixed) {

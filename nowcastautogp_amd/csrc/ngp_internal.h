@@ -109,8 +109,8 @@ struct ChunkPtrs {
     // staged value jobs on a lattice: the chunk's items split by the shape of their reduced program
     // (job-wide indices, ascending; item of the chunk = entry - fill_base); null: every item goes
     // through the general fill
-    const int32_t *fill_chain, *fill_other;
-    int32_t n_fill_chain, n_fill_other, fill_base;
+    const int32_t *fill_chain, *fill_other, *fill_single;
+    int32_t n_fill_chain, n_fill_other, n_fill_single, fill_base;
     const int32_t *items; // refinement sweeps: the items (indices into the chunk) a launch works
                           // on, Bc = their count; null: all of them in order
 };

@@ -578,6 +578,71 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
     }
 }
 
+// Stationary trees (the whole reduced program is ONE table: 45 of the 64 base kernels of the bench
+// ensemble): K[i][j] = tab[|q_i - q_j|].  No program in LDS, no interpreter: sixteen lookups in
+// flight per thread at full occupancy.  `p.fill_single` lists the chunk's such items.
+__global__ __launch_bounds__(256) void fill_single_kernel(JobGeom g, ChunkPtrs p, int ntri,
+                                                          DevSpec sp) {
+    const int item = p.fill_single[blockIdx.y] - p.fill_base;
+    const int tile = blockIdx.x;
+    int r, c;
+    bool aux = false;
+    if (tile < ntri) {
+        r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+        while (r * (r + 1) / 2 > tile) --r;
+        c = tile - r * (r + 1) / 2;
+    } else {
+        const int a = tile - ntri;
+        r = a / g.nb0;
+        c = a % g.nb0;
+        aux = true;
+    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = c * NB + 2 * tx;
+    const int q2a = p.qpts[col], q2b = p.qpts[col + 1];
+    const double diag = p.progs[item].noise + sp.jitter;
+    double *Lit = p.L + (long)item * g.item_stride;
+    const double *tab = p.tab + (long)item * g.maxstat * g.R;   // slot 0: the tree's only table
+    const int naux_t = g.da + g.m;
+    const double *y0 = p.y0 + (g.y_shared ? 0 : (long)item * g.n0);
+    f64x2 v[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        int pt = r * NB + ty * 8 + rr;
+        if (aux) pt = (pt < naux_t) ? g.n0 + pt : 0;
+        const int q1 = p.qpts[pt];
+        v[rr].x = tab[abs(q1 - q2a)];
+        v[rr].y = tab[abs(q1 - q2b)];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int lr = ty * 8 + rr;
+        f64x2 o = v[rr];
+        long row;
+        if (!aux) {
+            row = (long)r * NB + lr;
+            if (row == col) o.x += diag;
+            if (row == col + 1) o.y += diag;
+            if (row >= g.n_real || col >= g.n_real) o.x = (row == col) ? 1.0 : 0.0;
+            if (row >= g.n_real || col + 1 >= g.n_real) o.y = (row == col + 1) ? 1.0 : 0.0;
+        } else {
+            const int ar = r * NB + lr;
+            row = (long)g.n0 + ar;
+            if (ar == naux_t) {
+                o.x = y0[col];
+                o.y = y0[col + 1];
+            } else if (ar > naux_t) {
+                o.x = 0.0;
+                o.y = 0.0;
+            }
+        }
+        *reinterpret_cast<f64x2 *>(Lit + row * g.ld + col) = o;
+        if (aux && p.auxX)   // mixed-precision jobs keep the untouched aux rows X for the refinement
+            *reinterpret_cast<f64x2 *>(p.auxX + ((long)item * g.naux_pad + (row - g.n0)) * g.ld + col) = o;
+    }
+}
+
 // Chain programs (DevProgram::rchain with more than one instruction: one push, then only operations
 // that carry their leaf — 17 of the 19 non-stationary base kernels of the bench ensemble): every
 // instruction is decoded once per thread and applied to its 16 elements.  Same formulas and the
@@ -3387,6 +3452,9 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
             if (p.n_fill_chain > 0)
                 hipLaunchKernelGGL(fill_chain_kernel, dim3(ntiles, p.n_fill_chain), dim3(256), 0, s,
                                    g, p, ntri, sp);
+            if (p.n_fill_single > 0)
+                hipLaunchKernelGGL(fill_single_kernel, dim3(ntiles, p.n_fill_single), dim3(256), 0,
+                                   s, g, p, ntri, sp);
         } else {
             ChunkPtrs q = p;
             q.fill_other = nullptr;
