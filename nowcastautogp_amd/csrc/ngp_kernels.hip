@@ -679,110 +679,113 @@ __global__ __launch_bounds__(256) void fill_chain_kernel(JobGeom g, ChunkPtrs p,
     const double *sig = p.sig + (long)item * g.maxcp * g.npts;
     const int naux_t = g.da + g.m;
     const double *y0 = p.y0 + (g.y_shared ? 0 : (long)item * g.n0);
-    // lattice data of the thread's 8 rows (aux rows past the last time point: any valid point,
-    // the value is not used)
-    int q1[8], pt1[8];
-    double t1[8];
+    // Two passes of four rows: half the registers of one pass of eight (124 instead of 206 VGPRs:
+    // four waves per SIMD instead of two) for one more decode of the program per thread.  Lattice
+    // data of the rows first (aux rows past the last time point: any valid point, value unused).
+    for (int half = 0; half < 2; ++half) {
+        int q1[4], pt1[4];
+        double t1[4];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int lr = ty * 8 + rr;
-        int pt = r * NB + lr;
-        if (aux) pt = (pt < naux_t) ? g.n0 + pt : 0;
-        pt1[rr] = pt;
-        q1[rr] = p.qpts[pt];
-        t1[rr] = pt < g.n0 ? p.t0[pt] : p.taux[pt - g.n0];
-    }
-    double kv[8][2];
-    const int nops = P.n_rops;
-    for (int i = 0; i < nops; ++i) {
-        const int code = __builtin_amdgcn_readfirstlane((int)P.rops[i]);
-        const int op = code & 15;
-        int lk = code >> 4, lf;
-        if (i == 0) {
-            lk = (op == OP_TABLE) ? RLEAF_TABLE : RLEAF_LINEAR;
-            lf = __builtin_amdgcn_readfirstlane((int)(op == OP_TABLE ? P.rslot[0] : P.rpoff[0]));
-        } else {
-            lf = __builtin_amdgcn_readfirstlane((int)P.rleaf[i]);
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = ty * 8 + 4 * half + rr;
+            int pt = r * NB + lr;
+            if (aux) pt = (pt < naux_t) ? g.n0 + pt : 0;
+            pt1[rr] = pt;
+            q1[rr] = p.qpts[pt];
+            t1[rr] = pt < g.n0 ? p.t0[pt] : p.taux[pt - g.n0];
         }
-        double b[8][2];
-        if (lk == RLEAF_TABLE) {
-            const double *tb = tab + (long)lf * g.R;
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                b[rr][0] = tb[abs(q1[rr] - q2a)];
-                b[rr][1] = tb[abs(q1[rr] - q2b)];
+        double kv[4][2];
+        const int nops = P.n_rops;
+        for (int i = 0; i < nops; ++i) {
+            const int code = __builtin_amdgcn_readfirstlane((int)P.rops[i]);
+            const int op = code & 15;
+            int lk = code >> 4, lf;
+            if (i == 0) {
+                lk = (op == OP_TABLE) ? RLEAF_TABLE : RLEAF_LINEAR;
+                lf = __builtin_amdgcn_readfirstlane((int)(op == OP_TABLE ? P.rslot[0] : P.rpoff[0]));
+            } else {
+                lf = __builtin_amdgcn_readfirstlane((int)P.rleaf[i]);
             }
-        } else {
-            const double cc = P.params[lf], b0 = P.params[lf + 1], b1 = P.params[lf + 2];
+            double b[4][2];
+            if (lk == RLEAF_TABLE) {
+                const double *tb = tab + (long)lf * g.R;
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                b[rr][0] = b0 + b1 * (t1[rr] - cc) * (t2a - cc);
-                b[rr][1] = b0 + b1 * (t1[rr] - cc) * (t2b - cc);
+                for (int rr = 0; rr < 4; ++rr) {
+                    b[rr][0] = tb[abs(q1[rr] - q2a)];
+                    b[rr][1] = tb[abs(q1[rr] - q2b)];
+                }
+            } else {
+                const double cc = P.params[lf], b0 = P.params[lf + 1], b1 = P.params[lf + 2];
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    b[rr][0] = b0 + b1 * (t1[rr] - cc) * (t2a - cc);
+                    b[rr][1] = b0 + b1 * (t1[rr] - cc) * (t2b - cc);
+                }
             }
-        }
-        if (i == 0) {
+            if (i == 0) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                kv[rr][0] = b[rr][0];
-                kv[rr][1] = b[rr][1];
-            }
-        } else if (op == NGP_OP_PLUS) {
+                for (int rr = 0; rr < 4; ++rr) {
+                    kv[rr][0] = b[rr][0];
+                    kv[rr][1] = b[rr][1];
+                }
+            } else if (op == NGP_OP_PLUS) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                kv[rr][0] = kv[rr][0] + b[rr][0];
-                kv[rr][1] = kv[rr][1] + b[rr][1];
-            }
-        } else if (op == NGP_OP_TIMES) {
+                for (int rr = 0; rr < 4; ++rr) {
+                    kv[rr][0] = kv[rr][0] + b[rr][0];
+                    kv[rr][1] = kv[rr][1] + b[rr][1];
+                }
+            } else if (op == NGP_OP_TIMES) {
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                kv[rr][0] = kv[rr][0] * b[rr][0];
-                kv[rr][1] = kv[rr][1] * b[rr][1];
-            }
-        } else {
-            const int slot = __builtin_amdgcn_readfirstlane((int)P.rslot[i]);
-            const double *sg = sig + (long)slot * g.npts;
-            const double g2a = sg[col], g2b = sg[col + 1];
-            const bool fwd = op == NGP_OP_CHANGEPOINT;
+                for (int rr = 0; rr < 4; ++rr) {
+                    kv[rr][0] = kv[rr][0] * b[rr][0];
+                    kv[rr][1] = kv[rr][1] * b[rr][1];
+                }
+            } else {
+                const int slot = __builtin_amdgcn_readfirstlane((int)P.rslot[i]);
+                const double *sg = sig + (long)slot * g.npts;
+                const double g2a = sg[col], g2b = sg[col + 1];
+                const bool fwd = op == NGP_OP_CHANGEPOINT;
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const double g1 = sg[pt1[rr]];
+                for (int rr = 0; rr < 4; ++rr) {
+                    const double g1 = sg[pt1[rr]];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const double g2 = u ? g2b : g2a;
-                    const double kl = fwd ? kv[rr][u] : b[rr][u];
-                    const double kr = fwd ? b[rr][u] : kv[rr][u];
-                    kv[rr][u] = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+                    for (int u = 0; u < 2; ++u) {
+                        const double g2 = u ? g2b : g2a;
+                        const double kl = fwd ? kv[rr][u] : b[rr][u];
+                        const double kr = fwd ? b[rr][u] : kv[rr][u];
+                        kv[rr][u] = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+                    }
                 }
             }
         }
-    }
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int lr = ty * 8 + rr;
-        f64x2 v;
-        v.x = kv[rr][0];
-        v.y = kv[rr][1];
-        long row;
-        if (!aux) {
-            row = (long)r * NB + lr;
-            if (row == col) v.x += diag;
-            if (row == col + 1) v.y += diag;
-            if (row >= g.n_real || col >= g.n_real) v.x = (row == col) ? 1.0 : 0.0;
-            if (row >= g.n_real || col + 1 >= g.n_real) v.y = (row == col + 1) ? 1.0 : 0.0;
-        } else {
-            const int ar = r * NB + lr;
-            row = (long)g.n0 + ar;
-            if (ar == naux_t) {
-                v.x = y0[col];
-                v.y = y0[col + 1];
-            } else if (ar > naux_t) {
-                v.x = 0.0;
-                v.y = 0.0;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int lr = ty * 8 + 4 * half + rr;
+            f64x2 v;
+            v.x = kv[rr][0];
+            v.y = kv[rr][1];
+            long row;
+            if (!aux) {
+                row = (long)r * NB + lr;
+                if (row == col) v.x += diag;
+                if (row == col + 1) v.y += diag;
+                if (row >= g.n_real || col >= g.n_real) v.x = (row == col) ? 1.0 : 0.0;
+                if (row >= g.n_real || col + 1 >= g.n_real) v.y = (row == col + 1) ? 1.0 : 0.0;
+            } else {
+                const int ar = r * NB + lr;
+                row = (long)g.n0 + ar;
+                if (ar == naux_t) {
+                    v.x = y0[col];
+                    v.y = y0[col + 1];
+                } else if (ar > naux_t) {
+                    v.x = 0.0;
+                    v.y = 0.0;
+                }
             }
+            *reinterpret_cast<f64x2 *>(Lit + row * g.ld + col) = v;
+            if (aux && p.auxX)   // mixed-precision jobs keep the untouched aux rows X for the refinement
+                *reinterpret_cast<f64x2 *>(p.auxX + ((long)item * g.naux_pad + (row - g.n0)) * g.ld + col) = v;
         }
-        *reinterpret_cast<f64x2 *>(Lit + row * g.ld + col) = v;
-        if (aux && p.auxX)   // mixed-precision jobs keep the untouched aux rows X for the refinement
-            *reinterpret_cast<f64x2 *>(p.auxX + ((long)item * g.naux_pad + (row - g.n0)) * g.ld + col) = v;
     }
 }
 
