@@ -198,6 +198,12 @@ ngp_status ngp_logml_grad_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kerne
  * w_norm (P, may be NULL), ess, log_norm (log sum exp logw) out.              */
 ngp_status ngp_weights_normalize(int32_t P, const double *logw,
                                  double *w_norm, double *ess, double *log_norm);
+/* The same for D weight vectors at once — the D scenario clones forecast_with_nowcasts
+ * advances together (src/forecasting.jl:131-141): logw and w_norm are [P x D] row-major (one
+ * COLUMN per scenario, the layout of the all-gathered [P_local, D] shards), ess and log_norm
+ * are [D].  Column s equals ngp_weights_normalize on that column.                          */
+ngp_status ngp_weights_normalize_cols(int32_t P, int32_t D, const double *logw,
+                                      double *w_norm, double *ess, double *log_norm);
 
 /* ---- staged execution (inputs resident in HBM before the timed region) ----
  * stage  : validate, allocate device buffers, copy inputs host -> device
@@ -246,6 +252,17 @@ ngp_status ngp_mixture_sample(ngp_ctx *ctx, int32_t P, int32_t S, int32_t m,
                               const double *w, const double *mu, const double *sigma,
                               int32_t draws, uint64_t seed,
                               double *out, int32_t *comp, int32_t *info);
+/* S INDEPENDENT mixtures of P components each — the scenario clones after a refinement
+ * (mcmc_structure! / mcmc_parameters!, src/forecasting.jl:145-148) no longer share their
+ * particles:
+ *   w [S x P], mu [S x P x m], sigma [S x P x m x m], seeds [S],
+ *   out [S x draws x m], comp [S x draws] (may be NULL), info [S x P] (may be NULL).
+ * Mixture s is keyed by seeds[s] with scenario counter 0: it draws exactly what
+ * ngp_mixture_sample(P, S = 1, ..., seed = seeds[s]) draws, so one call replaces S calls.   */
+ngp_status ngp_mixture_sample_indep(ngp_ctx *ctx, int32_t P, int32_t S, int32_t m,
+                                    const double *w, const double *mu, const double *sigma,
+                                    int32_t draws, const uint64_t *seeds,
+                                    double *out, int32_t *comp, int32_t *info);
 
 /* ---- cached factor ------------------------------
  * A fitted model is queried many times with the same particles and the same

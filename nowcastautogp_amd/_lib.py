@@ -27,6 +27,7 @@ SYMBOLS = (
     "ngp_ctx_create", "ngp_ctx_destroy", "ngp_set_spec", "ngp_get_spec", "ngp_default_spec",
     "ngp_strerror", "ngp_version", "ngp_kernel_check", "ngp_cov_batch", "ngp_logml_batch",
     "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
+    "ngp_weights_normalize_cols", "ngp_mixture_sample_indep",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
     "ngp_job_mixed_stats", "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
     "ngp_factor_destroy", "ngp_mixture_sample", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
@@ -82,6 +83,9 @@ def load():
                                     i32, f64p, f64p, f64p, f64p, i32p]),
         "ngp_logml_grad_batch": (i32, [vp, i32, KP, i32, f64p, f64p, i64, f64p, f64p, i32p]),
         "ngp_weights_normalize": (i32, [i32, f64p, f64p, f64p, f64p]),
+        "ngp_weights_normalize_cols": (i32, [i32, i32, f64p, f64p, f64p, f64p]),
+        "ngp_mixture_sample_indep": (i32, [vp, i32, i32, i32, f64p, f64p, f64p, i32,
+                                           C.POINTER(C.c_uint64), f64p, i32p, i32p]),
         "ngp_logml_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, C.POINTER(vp)]),
         "ngp_predict_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, i32, f64p, i32,
                                     C.POINTER(vp)]),
@@ -140,6 +144,17 @@ def weights_normalize(logw):
     _chk(load().ngp_weights_normalize(logw.size, dptr(logw), dptr(w), C.byref(ess), C.byref(ln)),
          "ngp_weights_normalize")
     return w, float(ess.value), float(ln.value)
+
+
+def weights_normalize_cols(logw):
+    """``weights_normalize`` of every COLUMN of a [P, D] matrix in one call: (w [P, D], ess [D],
+    log_norm [D])."""
+    logw = as_f64(logw)
+    P, D = logw.shape
+    w, ess, ln = np.empty((P, D)), np.empty(D), np.empty(D)
+    _chk(load().ngp_weights_normalize_cols(P, D, dptr(logw), dptr(w), dptr(ess), dptr(ln)),
+         "ngp_weights_normalize_cols")
+    return w, ess, ln
 
 
 def _nullable(a: Optional[np.ndarray]):
@@ -357,6 +372,25 @@ class Context:
         _chk(load().ngp_mixture_sample(self._h, P, S, m, dptr(w), dptr(mu), dptr(sigma),
                                        int(draws), C.c_uint64(int(seed) & (2**64 - 1)), dptr(out),
                                        iptr(comp), iptr(info)), "ngp_mixture_sample")
+        return out, comp, info
+
+    def mixture_sample_indep(self, w, mu, sigma, draws: int, seeds):
+        """S independent mixtures of P components each (``ngp_mixture_sample_indep``): w [S,P],
+        mu [S,P,m], sigma [S,P,m,m], seeds [S] -> (out [S,draws,m], comp [S,draws], info [S,P]);
+        mixture s draws what ``mixture_sample`` with S = 1 and seed = seeds[s] draws."""
+        w, mu, sigma = as_f64(w), as_f64(mu), as_f64(sigma)
+        S, P = w.shape
+        m = mu.shape[2]
+        if mu.shape != (S, P, m) or sigma.shape != (S, P, m, m) or len(seeds) != S:
+            raise ValueError("mixture_sample_indep: w [S,P], mu [S,P,m], sigma [S,P,m,m], seeds [S]")
+        sd = np.array([int(v) & (2**64 - 1) for v in seeds], dtype=np.uint64)
+        out = np.empty((S, int(draws), m))
+        comp = np.zeros((S, int(draws)), dtype=np.int32)
+        info = np.zeros((S, P), dtype=np.int32)
+        _chk(load().ngp_mixture_sample_indep(self._h, P, S, m, dptr(w), dptr(mu), dptr(sigma),
+                                             int(draws), sd.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                             dptr(out), iptr(comp), iptr(info)),
+             "ngp_mixture_sample_indep")
         return out, comp, info
 
     def logml_grad_flat(self, ka: KernelArray, t, y):

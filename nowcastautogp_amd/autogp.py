@@ -78,6 +78,10 @@ class HipEngine:
         ``seed``; see include/ngp.h ``ngp_mixture_sample``)."""
         return self.ctx.mixture_sample(w, mu, sigma, draws, seed)
 
+    def mixture_sample_indep(self, w, mu, sigma, draws, seeds):
+        """Draws from S independent mixtures in one device call (``ngp_mixture_sample_indep``)."""
+        return self.ctx.mixture_sample_indep(w, mu, sigma, draws, seeds)
+
     def factor(self, programs, t, y):
         """Factorise once, keep L on the device (``ngp_factor``): repeated forecasts of a fitted
         model only pay for their appended / forecast rows."""
@@ -344,22 +348,40 @@ def maybe_resample(model: GPModel, ess_threshold: float) -> bool:
     passes ``ess_threshold * num_particles``, src/forecasting.jl:138-141).  Weights reset to
     uniform.  Across ranks: all-gather of log-weights, identical ancestors everywhere, particle
     descriptors exchanged — no matrix moves."""
-    w_loc, ess = _normalized_weights(model)
-    if not (ess < ess_threshold):
-        return False
-    sizes = distributed.block_sizes(model.n_particles_total)
-    w_all = distributed.all_gather_rows(w_loc[:, None], sizes=sizes)[:, 0]
-    seed = int(model.rng_shared.integers(0, 2**31 - 1))   # shared stream: same ancestors everywhere
-    anc = distributed.resample_ancestors(w_all, seed)
-    descr = [(p.program(), float(l)) for p, l in zip(model.particles, model._logml)]
-    mine = distributed.exchange_particles(descr, anc)
-    model.particles = [Particle(gp.from_program(pr[0], pr[1]), float(pr[2])) for pr, _ in mine]
-    model._logml = np.array([l for _, l in mine])
-    model.log_weights = np.zeros(len(mine))
-    model._gen += 1      # copies of one ancestor must not share its future draws
-    lo = distributed.shard(model.n_particles_total).start
-    model.prng = [particle_stream(model._root, model._gen, lo + i) for i in range(len(mine))]
-    return True
+    return maybe_resample_lockstep([model], ess_threshold)[0]
+
+
+def maybe_resample_lockstep(models: Sequence[GPModel], ess_threshold: float) -> List[bool]:
+    """``maybe_resample`` of D models at once (the scenario clones of forecast_with_nowcasts,
+    reference src/forecasting.jl:131-141): ONE all-gather of the [P_local, D] log-weights serves
+    every model's normalisation and ESS, and ONE exchange of particle descriptors serves every
+    model that resamples.  Model j draws its ancestors from its own shared stream, so the result
+    is what D separate calls give."""
+    P_total = models[0].n_particles_total
+    logw = np.stack([m.log_weights for m in models], axis=1)                 # [P_local, D]
+    _, ess, w_all = distributed.normalize_log_weights(logw, P_total=P_total, full=True)
+    need = [j for j in range(len(models)) if ess[j] < ess_threshold]
+    if not need:
+        return [False] * len(models)
+    ancs, descrs = [], []
+    for j in need:
+        m = models[j]
+        seed = int(m.rng_shared.integers(0, 2**31 - 1))   # shared stream: same ancestors everywhere
+        ancs.append(distributed.resample_ancestors(w_all[:, j], seed))
+        descrs.append([(p.program(), float(l)) for p, l in zip(m.particles, m._logml)])
+    mine = distributed.exchange_particles_many(descrs, ancs)
+    lo = distributed.shard(P_total).start
+    for j, got in zip(need, mine):
+        m = models[j]
+        m.particles = [Particle(gp.from_program(pr[0], pr[1]), float(pr[2])) for pr, _ in got]
+        m._logml = np.array([l for _, l in got])
+        m.log_weights = np.zeros(len(got))
+        m._gen += 1      # copies of one ancestor must not share its future draws
+        m.prng = [particle_stream(m._root, m._gen, lo + i) for i in range(len(got))]
+    done = [False] * len(models)
+    for j in need:
+        done[j] = True
+    return done
 
 
 # ---------------------------------------------------------------------------------------------
@@ -384,32 +406,60 @@ def _nodes(tree: gp.Node):
     return out
 
 
-def _structure_move(model: GPModel, t, y):
+def _group_obs(models: Sequence[GPModel]):
+    """(t, [y_j]): the observed data of models that advance in lockstep.  They must sit on the
+    same dates (the scenario clones of forecast_with_nowcasts do, reference
+    src/create_nowcast_data.jl:36-37); only the observations differ."""
+    t, y0 = models[0]._obs()
+    ys = [y0]
+    m0 = models[0]
+    d0 = np.sort(m0.days[m0._perm[:m0.n_obs]])
+    for m in models[1:]:
+        tj, yj = m._obs()
+        if (m.n_obs != m0.n_obs or m.ds_transform != m0.ds_transform
+                or not np.array_equal(np.sort(m.days[m._perm[:m.n_obs]]), d0)):
+            raise ValueError("models advanced in lockstep must share their observation dates")
+        ys.append(yj)
+    return t, ys
+
+
+def _item_y(ys, owner):
+    """The ``y`` argument of an engine call whose item i belongs to model ``owner[i]``: the one
+    shared vector for a single model, else one row per item (``ldy = n`` in include/ngp.h)."""
+    if len(ys) == 1:
+        return ys[0]
+    return np.stack(ys)[np.asarray(owner, dtype=np.int64)]
+
+
+def _structure_move(models: Sequence[GPModel], t, ys):
     """Subtree-regeneration Metropolis-Hastings: pick a node uniformly, redraw its subtree from
-    the prior; accept with min(1, L'/L * |T|/|T'|)."""
-    cfg = model.config
+    the prior; accept with min(1, L'/L * |T|/|T'|).  Every particle of every model proposes; ONE
+    engine call evaluates all proposals."""
     props, idx = [], []
-    for k, p in enumerate(model.particles):
-        rng = model.prng[k]
-        new = gp.clone(p.tree)
-        nodes = _nodes(new)
-        nd, depth, parent, side = nodes[int(rng.integers(len(nodes)))]
-        sub = gp.sample_tree(rng, cfg, depth=depth, depth_cap=model.depth_cap)
-        if parent is None:
-            new = sub
-        else:
-            setattr(parent, side, sub)
-        if _valid_program(new):
-            props.append(new)
-            idx.append(k)
+    for j, model in enumerate(models):
+        cfg = model.config
+        for k, p in enumerate(model.particles):
+            rng = model.prng[k]
+            new = gp.clone(p.tree)
+            nodes = _nodes(new)
+            nd, depth, parent, side = nodes[int(rng.integers(len(nodes)))]
+            sub = gp.sample_tree(rng, cfg, depth=depth, depth_cap=model.depth_cap)
+            if parent is None:
+                new = sub
+            else:
+                setattr(parent, side, sub)
+            if _valid_program(new):
+                props.append(new)
+                idx.append((j, k))
     if not props:
         return 0
-    progs = [gp.to_program(tr) + (model.particles[k].noise,) for tr, k in zip(props, idx)]
-    lm, info = model._eng().logml(progs, t, y)
+    progs = [gp.to_program(tr) + (models[j].particles[k].noise,) for tr, (j, k) in zip(props, idx)]
+    lm, info = models[0]._eng().logml(progs, t, _item_y(ys, [j for j, _ in idx]))
     acc = 0
-    for tr, k, l1, bad in zip(props, idx, lm, info):
+    for tr, (j, k), l1, bad in zip(props, idx, lm, info):
         if bad or not np.isfinite(l1):
             continue
+        model = models[j]
         log_a = (l1 - model._logml[k]) + math.log(model.particles[k].tree.size() / tr.size())
         if math.log(model.prng[k].random()) < log_a:
             model.particles[k].tree = tr
@@ -418,45 +468,47 @@ def _structure_move(model: GPModel, t, y):
     return acc
 
 
-def _latents(model: GPModel):
-    zs, kinds = [], []
-    for p in model.particles:
-        ops, params = gp.to_program(p.tree)
-        kd = gp.param_kinds(ops) + [gp.NOISE_KIND]
-        theta = np.concatenate([params, [p.noise]])
-        zs.append(gp.untransform(theta, kd, model.config.prior))
-        kinds.append(kd)
-    return zs, kinds
-
-
-def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
+def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float):
     """One HMC transition per particle on the N(0,1) latents z of (parameters, noise):
     U(z) = -log p(y | theta(z)) + |z|^2 / 2, gradient through the engine's logml gradient.
-    All particles move together: the latents live in one flat vector (``sl[k]`` is particle k's
-    slice), every leapfrog stage is one engine call and a handful of numpy operations."""
-    prior = model.config.prior
-    fixed_noise = model.config.noise is not None
-    P = len(model.particles)
-    z0, kinds = _latents(model)
-    ops = [gp.to_program(p.tree)[0] for p in model.particles]
+    All particles of all models move together: the latents live in one flat vector (``sl[i]`` is
+    item i's slice), every leapfrog stage is ONE engine call of P x D items (per-item y rows when
+    D > 1) and a handful of numpy operations."""
+    prior = models[0].config.prior
+    fixed_noise = models[0].config.noise is not None
+    items = [(j, k) for j, m in enumerate(models) for k in range(len(m.particles))]
+    B = len(items)
+    if B == 0:
+        return 0
+    part = [models[j].particles[k] for j, k in items]
+    prng = [models[j].prng[k] for j, k in items]
+    ops, z0 = [], []
+    codes_l = []
+    for p in part:
+        o, params = gp.to_program(p.tree)
+        kd = gp.param_kinds(o) + [gp.NOISE_KIND]
+        ops.append(o)
+        z0.append(gp.untransform(np.concatenate([params, [p.noise]]), kd, prior))
+        codes_l.extend(gp.KIND_CODES[k_] for k_ in kd)
     sizes = np.array([z.size for z in z0])
     off = np.concatenate([[0], np.cumsum(sizes)])
-    sl = [slice(int(off[k]), int(off[k + 1])) for k in range(P)]
-    seg = np.repeat(np.arange(P), sizes)                     # particle of every latent
-    codes = np.array([gp.KIND_CODES[k_] for kd in kinds for k_ in kd])
-    last = off[1:] - 1                                       # the noise latent of every particle
+    sl = [slice(int(off[i]), int(off[i + 1])) for i in range(B)]
+    seg = np.repeat(np.arange(B), sizes)                     # item of every latent
+    codes = np.array(codes_l)
+    last = off[1:] - 1                                       # the noise latent of every item
     positive = (codes == gp.KIND_CODES["wildcard"]) | (codes == gp.KIND_CODES["period"])
     is_gamma, is_unit = codes == gp.KIND_CODES["gamma"], codes == gp.KIND_CODES["unit"]
 
     is_param = np.ones(codes.size, dtype=bool)
     is_param[last] = False
-    eng = model._eng()
+    eng = models[0]._eng()
+    Y = _item_y(ys, [j for j, _ in items])
     ka = None
     if hasattr(eng, "logml_grad_flat"):
-        ka = eng.kernel_array([(ops[k], np.zeros(sizes[k] - 1), 0.0) for k in range(P)])
+        ka = eng.kernel_array([(ops[i], np.zeros(sizes[i] - 1), 0.0) for i in range(B)])
 
-    def sums(v):                                             # per-particle sums of a flat vector
-        return np.bincount(seg, weights=v, minlength=P)
+    def sums(v):                                             # per-item sums of a flat vector
+        return np.bincount(seg, weights=v, minlength=B)
 
     def potential(z):
         th, dth = gp.transform_flat(np.nan_to_num(z, nan=0.0, posinf=50.0, neginf=-50.0), codes,
@@ -469,10 +521,10 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
         th[is_unit] = np.clip(th[is_unit], 1e-9, 1.0 - 1e-9)
         if ka is not None:      # same structures, new parameters: refill the C array in place
             ka.set_params(th[is_param], th[last])
-            lm, g, info = eng.logml_grad_flat(ka, t, y)
+            lm, g, info = eng.logml_grad_flat(ka, t, Y)
         else:
-            progs = [(ops[k], th[sl[k]][:-1], float(th[last[k]])) for k in range(P)]
-            lm, grads, info = eng.logml_grad(progs, t, y)
+            progs = [(ops[i], th[sl[i]][:-1], float(th[last[i]])) for i in range(B)]
+            lm, grads, info = eng.logml_grad(progs, t, Y)
             g = np.concatenate(grads)
         with np.errstate(invalid="ignore", over="ignore"):
             ok = (np.asarray(info) == 0) & np.isfinite(lm) & (sums(~np.isfinite(g)) == 0)
@@ -484,7 +536,7 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
 
     z0 = np.concatenate(z0)
     U0, dU, _ = potential(z0)
-    mom = np.concatenate([model.prng[k].standard_normal(int(sizes[k])) for k in range(P)])
+    mom = np.concatenate([prng[i].standard_normal(int(sizes[i])) for i in range(B)])
     if fixed_noise:
         mom[last] = 0.0
     H0 = U0 + 0.5 * sums(mom * mom)
@@ -499,13 +551,13 @@ def _hmc_move(model: GPModel, t, y, n_leapfrog: int, eps: float):
         H1 = U1 + 0.5 * sums(pm * pm)
     th_new, _ = gp.transform_flat(z, codes, prior)
     acc = 0
-    for k in range(P):
-        u = model.prng[k].random()      # drawn for every particle: the stream does not depend on H
-        if np.isfinite(H1[k]) and math.log(u) < H0[k] - H1[k]:
-            th = th_new[sl[k]]
-            model.particles[k].tree = gp.from_program(ops[k], th[:-1])
-            model.particles[k].noise = float(th[-1])
-            model._logml[k] = float(lm1[k])
+    for i, (j, k) in enumerate(items):
+        u = prng[i].random()      # drawn for every particle: the stream does not depend on H
+        if np.isfinite(H1[i]) and math.log(u) < H0[i] - H1[i]:
+            th = th_new[sl[i]]
+            part[i].tree = gp.from_program(ops[i], th[:-1])
+            part[i].noise = float(th[-1])
+            models[j]._logml[k] = float(lm1[i])
             acc += 1
     return acc
 
@@ -514,21 +566,33 @@ DEFAULT_HMC = {"n_leapfrog": 10, "eps": 0.02}
 
 
 def mcmc_parameters(model: GPModel, n_hmc: int, hmc_config: Optional[dict] = None) -> None:
-    cfgd = {**DEFAULT_HMC, **(hmc_config or {})}
-    t, y = model._obs()
-    for _ in range(int(n_hmc)):
-        _hmc_move(model, t, y, cfgd["n_leapfrog"], cfgd["eps"])
+    mcmc_parameters_lockstep([model], n_hmc, hmc_config)
 
 
 def mcmc_structure(model: GPModel, n_mcmc: int, n_hmc: int, hmc_config: Optional[dict] = None,
                    biased: bool = False) -> None:
+    mcmc_structure_lockstep([model], n_mcmc, n_hmc, hmc_config, biased)
+
+
+def mcmc_parameters_lockstep(models: Sequence[GPModel], n_hmc: int,
+                             hmc_config: Optional[dict] = None) -> None:
+    """``mcmc_parameters!`` (reference src/forecasting.jl:65,148) for D models at once."""
+    cfgd = {**DEFAULT_HMC, **(hmc_config or {})}
+    t, ys = _group_obs(models)
+    for _ in range(int(n_hmc)):
+        _hmc_move(models, t, ys, cfgd["n_leapfrog"], cfgd["eps"])
+
+
+def mcmc_structure_lockstep(models: Sequence[GPModel], n_mcmc: int, n_hmc: int,
+                            hmc_config: Optional[dict] = None, biased: bool = False) -> None:
+    """``mcmc_structure!`` (reference src/forecasting.jl:146) for D models at once."""
     del biased  # accepted for signature compatibility; proposals are always drawn from the prior
-    t, y = model._obs()
+    t, ys = _group_obs(models)
     cfgd = {**DEFAULT_HMC, **(hmc_config or {})}
     for _ in range(int(n_mcmc)):
-        _structure_move(model, t, y)
+        _structure_move(models, t, ys)
         for _ in range(int(n_hmc)):
-            _hmc_move(model, t, y, cfgd["n_leapfrog"], cfgd["eps"])
+            _hmc_move(models, t, ys, cfgd["n_leapfrog"], cfgd["eps"])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -617,6 +681,15 @@ def predict_in_blocks(call, t_new: np.ndarray, blocks):
     return mu, sigma, info, extra
 
 
+def _append(model: GPModel, ds, y) -> int:
+    n_old = model.y.size
+    model.ds = model.ds + ds
+    model.days = np.concatenate([model.days, to_days(ds)])
+    model.y = np.concatenate([model.y, y])
+    model._perm = np.concatenate([model._perm, np.arange(n_old, n_old + y.size)])
+    return n_old + y.size
+
+
 def add_data(model: GPModel, ds, y) -> None:
     """Append observations; particle log-weights move by logml(n+d) - logml(n)
     (reference src/forecasting.jl:135)."""
@@ -625,15 +698,60 @@ def add_data(model: GPModel, ds, y) -> None:
         raise ValueError("ds and y must have the same length")
     if model.n_obs != model.y.size:
         raise RuntimeError("add_data on a model that has not absorbed all of its data")
-    n_old = model.y.size
-    model.ds = model.ds + ds
-    model.days = np.concatenate([model.days, to_days(ds)])
-    model.y = np.concatenate([model.y, y])
-    model._perm = np.concatenate([model._perm, np.arange(n_old, n_old + y.size)])
-    lm = _refresh_logml(model, n_old + y.size)
+    count = _append(model, ds, y)
+    lm = _refresh_logml(model, count)
     model.log_weights = _advance_weights(model.log_weights, lm, model._logml)
     model._logml = lm
-    model.n_obs = n_old + y.size
+    model.n_obs = count
+
+
+def add_data_lockstep(models: Sequence[GPModel], ds, ys, base: Optional[GPModel] = None) -> None:
+    """``add_data!`` (reference src/forecasting.jl:135) on D clones at once: model j absorbs
+    ``ys[j]`` on the shared dates ``ds``.
+
+    ``base``: the model all of them were cloned from and still equal (same particles, same
+    observed data).  The appended covariance rows then do not depend on the scenario, so the D
+    weight updates are ONE query of the base model's resident factor (``ngp_factor_nowcast``, or
+    ``ngp_nowcast_batch`` without one): P factorisations at most, instead of P x D.  Without
+    ``base`` it is one ``logml`` call of P x D items with per-item y rows."""
+    ds = list(ds)
+    ys = [np.asarray(y, dtype=np.float64) for y in ys]
+    if len(ys) != len(models) or any(len(ds) != y.size for y in ys):
+        raise ValueError("one vector of len(ds) observations per model")
+    if any(m.n_obs != m.y.size for m in models):
+        raise RuntimeError("add_data on a model that has not absorbed all of its data")
+    eng = models[0]._eng()
+    lms = None
+    if base is not None and hasattr(eng, "nowcast") and len(ds) > 0:
+        t, y = base._obs()
+        t_add = base.ds_transform.apply(to_days(ds))
+        y_add = np.stack([base.y_transform.apply(v) for v in ys])
+        from ._abi import NGP_MAX_AUX
+        if (t.size % 64) + t_add.size + 1 <= NGP_MAX_AUX:     # the appended rows fit one call
+            fac = base._factor()
+            o = (fac.nowcast(t_add, y_add, np.zeros(0), True) if fac is not None else
+                 eng.nowcast(base.programs(), t, y, t_add, y_add, np.zeros(0), True))
+            lf = np.asarray(o["logml_full"], dtype=np.float64)             # [P, D]
+            dead = (np.asarray(o["info"]) != 0)[:, None] | ~np.isfinite(lf)
+            lms = np.where(dead, -np.inf, lf)
+    counts = [_append(m, ds, y) for m, y in zip(models, ys)]
+    if lms is None:
+        t, yy = _group_obs_count(models, counts[0])
+        owner = [j for j, m in enumerate(models) for _ in m.particles]
+        lm, info = eng.logml([p for m in models for p in m.programs()], t, _item_y(yy, owner))
+        lm = np.where((np.asarray(info) != 0) | ~np.isfinite(lm), -np.inf, lm)
+        o = np.concatenate([[0], np.cumsum([len(m.particles) for m in models])])
+        lms = np.stack([lm[o[j]:o[j + 1]] for j in range(len(models))], axis=1)
+    for j, m in enumerate(models):
+        lm = np.array(lms[:, j])
+        m.log_weights = _advance_weights(m.log_weights, lm, m._logml)
+        m._logml = lm
+        m.n_obs = counts[j]
+
+
+def _group_obs_count(models, count):
+    t, y0 = models[0]._obs(count)
+    return t, [y0] + [m._obs(count)[1] for m in models[1:]]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -678,15 +796,29 @@ class MixtureMVN:
 
 
 def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
-    t, y = model._obs()
-    t_new = model.ds_transform.apply(to_days(list(ds)))
-    fac = model._factor()
+    return predict_mvn_lockstep([model], ds, noise_on_new)[0]
+
+
+def predict_mvn_lockstep(models: Sequence[GPModel], ds, noise_on_new: bool = True) -> List[MixtureMVN]:
+    """``predict_mvn`` (reference src/forecasting.jl:46,66) of D models on the same dates: ONE
+    engine call of P x D items (a single model goes through its resident factor), and in a
+    sharded run ONE all-gather that carries every model's means, covariances and weights."""
+    D = len(models)
+    t, ys = _group_obs(models)
+    t_new = models[0].ds_transform.apply(to_days(list(ds)))
+    eng = models[0]._eng()
+    fac = models[0]._factor() if D == 1 else None
+    if D > 1:
+        progs = [p for m in models for p in m.programs()]
+        Y = _item_y(ys, [j for j, m in enumerate(models) for _ in m.particles])
 
     def call(ts):
         if fac is not None:
             mu_s, sg_s, _, info_s = fac.predict(ts, noise_on_new)
+        elif D == 1:
+            mu_s, sg_s, _, info_s = eng.predict(models[0].programs(), t, ys[0], ts, noise_on_new)
         else:
-            mu_s, sg_s, _, info_s = model._eng().predict(model.programs(), t, y, ts, noise_on_new)
+            mu_s, sg_s, _, info_s = eng.predict(progs, t, Y, ts, noise_on_new)
         return mu_s, sg_s, info_s, None
 
     blocks = horizon_blocks(t.size, 0, t_new.size)
@@ -697,18 +829,50 @@ def predict_mvn(model: GPModel, ds, noise_on_new: bool = True) -> MixtureMVN:
     bad = np.flatnonzero(info)
     if bad.size:
         raise PosDefException(int(info[bad[0]]), int(bad[0]))
-    s = model.y_transform.slope
-    means = (mu - model.y_transform.intercept) / s
-    covs = sigma / (s * s)
-    w, _ = _normalized_weights(model)
-    if distributed.world()[1] > 1:   # every rank returns the full mixture
-        sizes = distributed.block_sizes(model.n_particles_total)
-        means = distributed.all_gather_rows(means, sizes=sizes)
-        covs = distributed.all_gather_rows(covs.reshape(covs.shape[0], -1), sizes=sizes).reshape(
-            (-1,) + covs.shape[1:])
-        w = distributed.all_gather_rows(w[:, None], sizes=sizes)[:, 0]
+    m = t_new.size
+    off = np.concatenate([[0], np.cumsum([len(mm.particles) for mm in models])])
+    P_total = models[0].n_particles_total
+    logw = np.stack([mm.log_weights for mm in models], axis=1)
+    w, _ = distributed.normalize_log_weights(logw, P_total=P_total)           # [P_local, D]
+    means, covs = [], []
+    for j, mm in enumerate(models):
+        sl_ = mm.y_transform.slope
+        means.append((mu[off[j]:off[j + 1]] - mm.y_transform.intercept) / sl_)
+        covs.append(sigma[off[j]:off[j + 1]] / (sl_ * sl_))
+    if distributed.world()[1] > 1:   # every rank returns the full mixtures: one collective
+        P_loc = w.shape[0]
+        packed = np.concatenate(
+            [np.stack(means, axis=1).reshape(P_loc, D * m),
+             np.stack(covs, axis=1).reshape(P_loc, D * m * m), w], axis=1)
+        packed = distributed.all_gather_rows(packed, sizes=distributed.block_sizes(P_total))
+        mm_, cc_ = packed[:, :D * m].reshape(-1, D, m), packed[:, D * m:D * m * (m + 1)].reshape(
+            -1, D, m, m)
+        w = packed[:, D * m * (m + 1):]
+        means = [np.ascontiguousarray(mm_[:, j]) for j in range(D)]
+        covs = [np.ascontiguousarray(cc_[:, j]) for j in range(D)]
     # shared stream: the same draws on every rank; the device sampler takes at most NGP_MAX_AUX
     # dates, longer horizons are drawn on the host
     from ._abi import NGP_MAX_AUX
-    sampler = getattr(model._eng(), "mixture_sample", None) if t_new.size <= NGP_MAX_AUX else None
-    return MixtureMVN(means, covs, w, model.rng_shared, sampler)
+    sampler = getattr(eng, "mixture_sample", None) if t_new.size <= NGP_MAX_AUX else None
+    return [MixtureMVN(means[j], covs[j], w[:, j], mm.rng_shared, sampler)
+            for j, mm in enumerate(models)]
+
+
+def rand_lockstep(mixes: Sequence[MixtureMVN], draws: int, engine=None) -> List[np.ndarray]:
+    """``rand(dist, draws)`` (reference src/forecasting.jl:47) for D mixtures: with the device
+    sampler ONE call (``ngp_mixture_sample_indep``: mixture j keyed by the seed its own stream
+    gives, so the draws are those of D separate ``rand`` calls); otherwise mixture by mixture."""
+    multi = getattr(engine, "mixture_sample_indep", None)
+    k = int(draws)
+    m = mixes[0].means.shape[1]
+    P = mixes[0].means.shape[0]
+    if (multi is None or len(mixes) < 2 or k <= 1 or m == 0
+            or any(mx.sampler is None or mx.means.shape != (P, m) for mx in mixes)):
+        return [mx.rand(k) for mx in mixes]
+    seeds = [int(mx.rng.integers(0, 2**63 - 1)) for mx in mixes]
+    out, _, info = multi(np.stack([mx.weights for mx in mixes]), np.stack([mx.means for mx in mixes]),
+                         np.stack([mx.covs for mx in mixes]), k, seeds)
+    bad = np.argwhere(info != 0)
+    if bad.size:
+        raise PosDefException(int(info[tuple(bad[0])]), int(bad[0][1]))
+    return [np.ascontiguousarray(out[j].T) for j in range(len(mixes))]

@@ -1538,73 +1538,113 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     return NGP_OK;
 }
 
-extern "C" ngp_status ngp_weights_normalize(int32_t P, const double *logw, double *w_norm,
-                                            double *ess, double *log_norm) {
-    if (P <= 0 || !logw) return NGP_ERR_ARG;
+// one column of a [P x ld]-strided log-weight matrix (ld = 1: a plain vector)
+static void weights_normalize_strided(int P, const double *logw, long ld, double *w_norm, long ldw,
+                                      double *ess, double *log_norm) {
     // a particle whose factorisation failed carries -inf (or NaN after -inf - -inf): weight 0, it
     // must not poison the others
     double mx = -INFINITY;
     for (int i = 0; i < P; ++i)
-        if (std::isfinite(logw[i]) && logw[i] > mx) mx = logw[i];
+        if (std::isfinite(logw[i * ld]) && logw[i * ld] > mx) mx = logw[i * ld];
     if (!(mx > -INFINITY)) {
         if (ess) *ess = NAN;
         if (log_norm) *log_norm = -INFINITY;
-        if (w_norm) for (int i = 0; i < P; ++i) w_norm[i] = NAN;
-        return NGP_OK;
+        if (w_norm) for (int i = 0; i < P; ++i) w_norm[i * ldw] = NAN;
+        return;
     }
-    auto e = [&](int i) { return std::isfinite(logw[i]) ? std::exp(logw[i] - mx) : 0.0; };
+    auto e = [&](int i) { return std::isfinite(logw[i * ld]) ? std::exp(logw[i * ld] - mx) : 0.0; };
     double sum = 0.0;
     for (int i = 0; i < P; ++i) sum += e(i);
     double sq = 0.0;
     for (int i = 0; i < P; ++i) {
         const double w = e(i) / sum;
-        if (w_norm) w_norm[i] = w;
+        if (w_norm) w_norm[i * ldw] = w;
         sq += w * w;
     }
     if (ess) *ess = 1.0 / sq;
     if (log_norm) *log_norm = mx + std::log(sum);
+}
+
+extern "C" ngp_status ngp_weights_normalize(int32_t P, const double *logw, double *w_norm,
+                                            double *ess, double *log_norm) {
+    if (P <= 0 || !logw) return NGP_ERR_ARG;
+    weights_normalize_strided(P, logw, 1, w_norm, 1, ess, log_norm);
     return NGP_OK;
 }
 
-extern "C" ngp_status ngp_mixture_sample(ngp_ctx *c, int32_t P, int32_t S, int32_t m,
-                                         const double *w, const double *mu, const double *sigma,
-                                         int32_t draws, uint64_t seed, double *out, int32_t *comp,
-                                         int32_t *info) {
+extern "C" ngp_status ngp_weights_normalize_cols(int32_t P, int32_t D, const double *logw,
+                                                 double *w_norm, double *ess, double *log_norm) {
+    if (P <= 0 || D <= 0 || !logw) return NGP_ERR_ARG;
+    for (int s = 0; s < D; ++s)
+        weights_normalize_strided(P, logw + s, D, w_norm ? w_norm + s : nullptr, D,
+                                  ess ? ess + s : nullptr, log_norm ? log_norm + s : nullptr);
+    return NGP_OK;
+}
+
+// shared body of ngp_mixture_sample (seeds == nullptr: S mixtures over the SAME P components,
+// mu [P x S x m], sigma [P x m x m], one key) and ngp_mixture_sample_indep (seeds [S]: every
+// mixture has its own P components, mu [S x P x m], sigma [S x P x m x m], its own key)
+static ngp_status mixture_sample_impl(ngp_ctx *c, int32_t P, int32_t S, int32_t m, const double *w,
+                                      const double *mu, const double *sigma, int32_t draws,
+                                      uint64_t seed, const uint64_t *seeds, double *out,
+                                      int32_t *comp, int32_t *info) {
     if (!c || !w || !mu || !sigma || !out || P <= 0 || S <= 0 || m <= 0 || draws <= 0)
         return NGP_ERR_ARG;
     if (m > NGP_MAX_AUX) return NGP_ERR_TOO_LARGE;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const size_t nw = (size_t)S * P, nmu = (size_t)P * S * m, nsg = (size_t)P * m * m,
+    const size_t ncomp_mats = seeds ? (size_t)S * P : (size_t)P;
+    const size_t nw = (size_t)S * P, nmu = (size_t)P * S * m, nsg = ncomp_mats * m * m,
                  nout = (size_t)S * draws * m, ncomp = (size_t)S * draws;
     void *dw = nullptr, *dmu = nullptr, *dsg = nullptr, *dout = nullptr, *dcomp = nullptr,
-         *dinfo = nullptr;
+         *dinfo = nullptr, *dseeds = nullptr;
     auto freeall = [&] {
         c->release(dw); c->release(dmu); c->release(dsg); c->release(dout); c->release(dcomp);
-        c->release(dinfo);
+        c->release(dinfo); c->release(dseeds);
     };
     ngp_status st;
     if ((st = c->alloc(&dw, 8 * nw)) || (st = c->alloc(&dmu, 8 * nmu)) ||
         (st = c->alloc(&dsg, 8 * nsg)) || (st = c->alloc(&dout, 8 * nout)) ||
-        (st = c->alloc(&dcomp, 4 * ncomp)) || (st = c->alloc(&dinfo, 4 * (size_t)P))) {
+        (st = c->alloc(&dcomp, 4 * ncomp)) || (st = c->alloc(&dinfo, 4 * ncomp_mats)) ||
+        (seeds && (st = c->alloc(&dseeds, 8 * (size_t)S)))) {
         freeall();
         return st;
     }
     hipError_t e = hipMemcpyAsync(dw, w, 8 * nw, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(dmu, mu, 8 * nmu, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(dsg, sigma, 8 * nsg, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && seeds)
+        e = hipMemcpyAsync(dseeds, seeds, 8 * (size_t)S, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         launch_mixture_sample(P, S, m, (const double *)dw, (const double *)dmu, (double *)dsg, draws,
-                              seed, (double *)dout, (int32_t *)dcomp, (int32_t *)dinfo, s);
+                              seed, (const uint64_t *)dseeds, (double *)dout, (int32_t *)dcomp,
+                              (int32_t *)dinfo, s);
         e = hipMemcpyAsync(out, dout, 8 * nout, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess && comp) e = hipMemcpyAsync(comp, dcomp, 4 * ncomp, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && info) e = hipMemcpyAsync(info, dinfo, 4 * (size_t)P, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && info)
+        e = hipMemcpyAsync(info, dinfo, 4 * ncomp_mats, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();
     freeall();
     return e == hipSuccess ? NGP_OK : (ngp_status)e;
+}
+
+extern "C" ngp_status ngp_mixture_sample(ngp_ctx *c, int32_t P, int32_t S, int32_t m,
+                                         const double *w, const double *mu, const double *sigma,
+                                         int32_t draws, uint64_t seed, double *out, int32_t *comp,
+                                         int32_t *info) {
+    return mixture_sample_impl(c, P, S, m, w, mu, sigma, draws, seed, nullptr, out, comp, info);
+}
+
+extern "C" ngp_status ngp_mixture_sample_indep(ngp_ctx *c, int32_t P, int32_t S, int32_t m,
+                                               const double *w, const double *mu,
+                                               const double *sigma, int32_t draws,
+                                               const uint64_t *seeds, double *out, int32_t *comp,
+                                               int32_t *info) {
+    if (!seeds) return NGP_ERR_ARG;
+    return mixture_sample_impl(c, P, S, m, w, mu, sigma, draws, 0, seeds, out, comp, info);
 }
 
 // ---------------------------------------------------------------------------------------

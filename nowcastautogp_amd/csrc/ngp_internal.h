@@ -175,8 +175,8 @@ void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipS
 void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2,
                 int n2, int add_diag, double *out, const DevSpec &sp, hipStream_t s);
 void launch_mixture_sample(int P, int S, int m, const double *w, const double *mu, double *chol,
-                           int draws, uint64_t seed, double *out, int32_t *comp, int32_t *info,
-                           hipStream_t s);
+                           int draws, uint64_t seed, const uint64_t *seeds, double *out,
+                           int32_t *comp, int32_t *info, hipStream_t s);
 void launch_mfma_bench(double *out, int iters, int blocks, hipStream_t s);
 void launch_mfma_bench_detail(unsigned long long *stamps, int iters, int blocks, hipStream_t s);
 void launch_mfma_layout_probe(const double *A, const double *Bm, double *Dout, hipStream_t s);

@@ -3297,16 +3297,27 @@ __global__ __launch_bounds__(256) void small_chol_kernel(double *A, int m, int32
     if (tid == 0 && info) info[blockIdx.x] = bad;
 }
 
-// one thread per (scenario, draw)
+// one thread per (scenario, draw).  seeds == nullptr: the S mixtures share their P components
+// (mu [P][S][m], chol [P][m][m]) and one key, the scenario index is part of the counter.
+// seeds != nullptr: S independent mixtures (mu [S][P][m], chol [S][P][m][m]); mixture s is keyed
+// by seeds[s] with scenario counter 0, i.e. it draws exactly what a call with S = 1 and
+// seed = seeds[s] draws.
 __global__ __launch_bounds__(256) void mixture_sample_kernel(int P, int S, int m, const double *w,
                                                              const double *mu, const double *chol,
                                                              int draws, unsigned k0, unsigned k1,
+                                                             const unsigned long long *seeds,
                                                              double *out, int32_t *comp) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long)S * draws) return;
     const int s = (int)(idx / draws), d = (int)(idx % draws);
+    unsigned cs = (unsigned)s;
+    if (seeds) {
+        k0 = (unsigned)seeds[s];
+        k1 = (unsigned)(seeds[s] >> 32);
+        cs = 0u;
+    }
     // block 0: component pick by inverse CDF over the P weights of scenario s
-    const Philox4 r0 = philox4x32_10(Philox4{(unsigned)d, (unsigned)s, 0u, 0u}, k0, k1);
+    const Philox4 r0 = philox4x32_10(Philox4{(unsigned)d, cs, 0u, 0u}, k0, k1);
     const double u = u01(r0.x, r0.y);
     const double *ws = w + (long)s * P;
     int k = P - 1;
@@ -3317,12 +3328,12 @@ __global__ __launch_bounds__(256) void mixture_sample_kernel(int P, int S, int m
     }
     if (comp) comp[idx] = k;
     // blocks 1..: four words -> one Box-Muller pair -> two normals
-    const double *L = chol + (long)k * m * m;
-    const double *mk = mu + ((long)k * S + s) * m;
+    const double *L = chol + ((seeds ? (long)s * P : 0l) + k) * m * m;
+    const double *mk = mu + (seeds ? ((long)s * P + k) : ((long)k * S + s)) * m;
     double *o = out + idx * m;
     for (int i = 0; i < m; ++i) o[i] = mk[i];
     for (int j0 = 0; j0 < m; j0 += 2) {
-        const Philox4 r = philox4x32_10(Philox4{(unsigned)d, (unsigned)s, (unsigned)(1 + j0 / 2), 0u},
+        const Philox4 r = philox4x32_10(Philox4{(unsigned)d, cs, (unsigned)(1 + j0 / 2), 0u},
                                         k0, k1);
         const double u1 = u01(r.x, r.y), u2 = u01(r.z, r.w);
         const double rad = sqrt(-2.0 * log(u1)), ang = 2.0 * M_PI * u2;
@@ -3334,13 +3345,14 @@ __global__ __launch_bounds__(256) void mixture_sample_kernel(int P, int S, int m
 }
 
 void launch_mixture_sample(int P, int S, int m, const double *w, const double *mu, double *chol,
-                           int draws, uint64_t seed, double *out, int32_t *comp, int32_t *info,
-                           hipStream_t s) {
-    hipLaunchKernelGGL(small_chol_kernel, dim3(P), dim3(256), 0, s, chol, m, info);
+                           int draws, uint64_t seed, const uint64_t *seeds, double *out,
+                           int32_t *comp, int32_t *info, hipStream_t s) {
+    const long mats = seeds ? (long)S * P : (long)P;
+    hipLaunchKernelGGL(small_chol_kernel, dim3((unsigned)mats), dim3(256), 0, s, chol, m, info);
     const long n = (long)S * draws;
     hipLaunchKernelGGL(mixture_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, P,
                        S, m, w, mu, (const double *)chol, draws, (unsigned)seed,
-                       (unsigned)(seed >> 32), out, comp);
+                       (unsigned)(seed >> 32), (const unsigned long long *)seeds, out, comp);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -102,12 +102,14 @@ def block_sizes(P_total: int, size: Optional[int] = None) -> np.ndarray:
                      for r in range(size)], dtype=np.int64)
 
 
-def normalize_log_weights(logw_local: np.ndarray, device=None, P_total: Optional[int] = None):
+def normalize_log_weights(logw_local: np.ndarray, device=None, P_total: Optional[int] = None,
+                          full: bool = False):
     """logw_local: [P_local] or [P_local, D] (one column per scenario).  Returns this rank's
     slice of the normalised weights and the effective sample size per column, both computed
     over ALL ranks' particles through the C-ABI's ngp_weights_normalize.  ONE collective when the
     caller states ``P_total`` (the block partition then gives every rank's row count); otherwise a
-    second small one finds the counts."""
+    second small one finds the counts.  ``full``: also return the normalised weights of ALL
+    particles ([P_total] / [P_total, D]) — what resampling needs, without a second all-gather."""
     lw = np.asarray(logw_local, dtype=np.float64)
     one = lw.ndim == 1
     if one:
@@ -119,13 +121,11 @@ def normalize_log_weights(logw_local: np.ndarray, device=None, P_total: Optional
     allw = all_gather_rows(lw, device, sizes)
     r, _ = world()
     lo = int(sizes[:r].sum())
-    w = np.empty_like(lw)
-    ess = np.empty(lw.shape[1])
-    for s in range(lw.shape[1]):
-        wn, e, _ = _lib.weights_normalize(allw[:, s])
-        w[:, s] = wn[lo:lo + lw.shape[0]]
-        ess[s] = e
-    return (w[:, 0], float(ess[0])) if one else (w, ess)
+    w_all, ess, _ = _lib.weights_normalize_cols(allw)
+    w = w_all[lo:lo + lw.shape[0]]
+    if one:
+        return (w[:, 0], float(ess[0]), w_all[:, 0]) if full else (w[:, 0], float(ess[0]))
+    return (w, ess, w_all) if full else (w, ess)
 
 
 def resample_ancestors(weights_all: np.ndarray, seed: int) -> np.ndarray:
@@ -139,11 +139,20 @@ def exchange_particles(local: Sequence, ancestors: np.ndarray) -> List:
     """After resampling, rank r keeps particles ancestors[shard(r)]; descriptors (kernel program +
     noise, < 1 KiB each) are all-gathered so every rank can rebuild its new particles.  No matrix
     ever crosses xGMI."""
+    return exchange_particles_many([local], [ancestors])[0]
+
+
+def exchange_particles_many(locals_: Sequence[Sequence], ancestors: Sequence[np.ndarray]) -> List[List]:
+    """``exchange_particles`` for several ensembles that resample at the same time (the scenario
+    clones of forecast_with_nowcasts): ONE all-gather carries every ensemble's descriptors."""
     d = _dist()
     if d is None or d.get_world_size() == 1:
-        return [local[int(a)] for a in ancestors]
+        return [[loc[int(a)] for a in anc] for loc, anc in zip(locals_, ancestors)]
     gathered: List = [None] * d.get_world_size()
-    d.all_gather_object(gathered, list(local))
-    flat = [p for part in gathered for p in part]
-    mine = shard(len(flat))
-    return [flat[int(a)] for a in ancestors[mine]]
+    d.all_gather_object(gathered, [list(loc) for loc in locals_])
+    out = []
+    for j, anc in enumerate(ancestors):
+        flat = [p for part in gathered for p in part[j]]
+        mine = shard(len(flat))
+        out.append([flat[int(a)] for a in anc[mine]])
+    return out

@@ -5,11 +5,16 @@ src/forecasting.jl:29-167), plus the small containers their signatures need (``T
 src/create_nowcast_data.jl:27-76).  Same names, argument meaning and error behaviour, so the
 reference's shape / assertion tests read the same against this module (tests/test_mirror_*.py).
 
-What is different by design: ``forecast_with_nowcasts`` does not fan scenarios out as tasks.  On
-the default path (``n_mcmc = n_hmc = 0``, ``forecast_n_hmc = None``) all scenarios share the
-appended dates and K does not depend on y, so ONE batched call (``ngp_nowcast_batch``) factorises
-every particle once and returns every scenario's weight update and predictive mean; with
-refinement requested it falls back to the reference's per-scenario loop on cloned models.
+What is different by design: ``forecast_with_nowcasts`` does not fan scenarios out as tasks
+(reference src/forecasting.jl:131-132: one ``Threads.@spawn`` per scenario).  On the default path
+(``n_mcmc = n_hmc = 0``, ``forecast_n_hmc = None``) all scenarios share the appended dates and K
+does not depend on y, so ONE batched call (``ngp_nowcast_batch``) factorises every particle once
+and returns every scenario's weight update and predictive mean.  With refinement requested
+(``mcmc_structure!`` / ``mcmc_parameters!`` after the nowcast, or HMC before every draw) the D
+scenario clones advance in LOCKSTEP: every proposal / leapfrog / prediction is one engine call of
+P x D items with per-item y rows — the device sees the reference's whole task fan-out as one batch
+instead of D small ones.  Every clone keeps its own random streams, so the result is that of the
+reference's per-scenario loop (``lockstep=False``) for the same seed.
 """
 from __future__ import annotations
 
@@ -131,11 +136,30 @@ def forecast(model: GPModel, forecast_dates, forecast_draws: int, *,
     return _apply(inv_transformation, draws)
 
 
+def forecast_lockstep(models: Sequence[GPModel], forecast_dates, forecast_draws: int, *,
+                      inv_transformation: Callable = lambda y: y,
+                      forecast_n_hmc: Optional[int] = None) -> List[np.ndarray]:
+    """``forecast`` (reference src/forecasting.jl:29-75) of D models on the same dates at once."""
+    dates = list(forecast_dates)
+    k = int(forecast_draws)
+    if forecast_n_hmc is None:
+        mixes = autogp.predict_mvn_lockstep(models, dates)
+        out = autogp.rand_lockstep(mixes, k, models[0]._eng())
+    else:
+        out = [np.empty((len(dates), k)) for _ in models]
+        for i in range(k):       # src/forecasting.jl:63-68: HMC on the parameters before every draw
+            autogp.mcmc_parameters_lockstep(models, forecast_n_hmc)
+            for o, mix in zip(out, autogp.predict_mvn_lockstep(models, dates)):
+                o[:, i] = mix.rand()
+    return [_apply(inv_transformation, o) for o in out]
+
+
 def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forecast_dates,
                            forecast_draws_per_nowcast: int, *,
                            inv_transformation: Callable = lambda y: y, n_mcmc: int = 0,
                            n_hmc: int = 0, ess_threshold: float = 0.0,
-                           forecast_n_hmc: Optional[int] = None, verbose: bool = False) -> np.ndarray:
+                           forecast_n_hmc: Optional[int] = None, verbose: bool = False,
+                           lockstep: bool = True) -> np.ndarray:
     assert len(nowcasts) > 0, "nowcasts vector must not be empty"
     assert not (n_mcmc > 0 and n_hmc == 0), \
         "If n_mcmc > 0, n_hmc must also be > 0 for MCMC refinement"
@@ -144,19 +168,38 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
     dates = list(forecast_dates)
     draws = int(forecast_draws_per_nowcast)
     same_dates = all(list(nc.ds) == list(nowcasts[0].ds) for nc in nowcasts)
-    single = autogp.distributed.world()[1] == 1
-    if n_mcmc == 0 and n_hmc == 0 and forecast_n_hmc is None and same_dates and single:
+    if n_mcmc == 0 and n_hmc == 0 and forecast_n_hmc is None and same_dates and lockstep:
         return _forecast_with_nowcasts_batched(base_model, nowcasts, dates, draws,
                                                inv_transformation, ess_threshold)
     base = base_model.to_dict()
-    results = []
-    for nc in nowcasts:   # the reference's per-scenario task, sequential here
+
+    def clone():
         m = GPModel.from_dict(copy.deepcopy(base), engine=base_model.engine)
         # every scenario is its own task with its own randomness in the reference
         # (src/forecasting.jl:131-133); a clone that kept the snapshot's stream would repeat the
         # first scenario's draws.  Splitting also advances the base model's streams, so a second
         # call differs from the first.
         m.reseed(int(base_model.rng_shared.integers(0, 2**62)))
+        return m
+
+    if lockstep and same_dates:
+        # the reference's D tasks as ONE ensemble of P x D items (src/forecasting.jl:131-159)
+        models = [clone() for _ in nowcasts]
+        autogp.add_data_lockstep(models, nowcasts[0].ds, [nc.y for nc in nowcasts],
+                                 base=base_model)
+        autogp.maybe_resample_lockstep(models, ess_threshold * autogp.num_particles(base_model))
+        if n_mcmc > 0 and n_hmc > 0:
+            autogp.mcmc_structure_lockstep(models, n_mcmc, n_hmc)
+        elif n_mcmc == 0 and n_hmc > 0:
+            autogp.mcmc_parameters_lockstep(models, n_hmc)
+        results = forecast_lockstep(models, dates, draws, inv_transformation=inv_transformation,
+                                    forecast_n_hmc=forecast_n_hmc)
+        if verbose:
+            print(f"Nowcast scenarios: {len(results)}/{len(nowcasts)} (lockstep)")
+        return np.hstack(results)
+    results = []
+    for nc in nowcasts:   # the reference's per-scenario task, one after another
+        m = clone()
         autogp.add_data(m, nc.ds, nc.y)
         autogp.maybe_resample(m, ess_threshold * autogp.num_particles(m))
         if n_mcmc > 0 and n_hmc > 0:
@@ -198,39 +241,45 @@ def _forecast_with_nowcasts_batched(model, nowcasts, dates, draws, inv_transform
     if bad.size:
         raise autogp.PosDefException(int(out["info"][bad[0]]), int(bad[0]))
     s, b = model.y_transform.slope, model.y_transform.intercept
-    covs = out["sigma"] / (s * s)
-    P = len(model.particles)
-    rng = model.rng_shared
     D = len(nowcasts)
+    m = len(dates)
+    P = model.n_particles_total
+    rng = model.rng_shared          # shared stream: every rank makes the same draws
+    # add_data! weight update for every scenario, normalised over ALL ranks' particles: one
+    # all-gather of [P_local, D] log-weights (the only collective of the weight update)
+    dist_ = autogp.distributed
+    logw = model.log_weights[:, None] + (out["logml_full"] - out["logml_base"][:, None])
+    _, ess, w_all = dist_.normalize_log_weights(logw, P_total=P, full=True)
+    w = np.ascontiguousarray(w_all.T)                                         # [D, P]
+    means = (out["mu"] - b) / s if m else np.zeros((logw.shape[0], D, 0))     # [P_local, D, m]
+    covs = out["sigma"] / (s * s) if m else np.zeros((logw.shape[0], 0, 0))
+    if dist_.world()[1] > 1:        # the mixtures need every rank's components: one more
+        packed = np.concatenate([means.reshape(means.shape[0], -1),
+                                 covs.reshape(covs.shape[0], -1)], axis=1)
+        packed = dist_.all_gather_rows(packed, sizes=dist_.block_sizes(P))
+        means = np.ascontiguousarray(packed[:, :D * m].reshape(P, D, m))
+        covs = np.ascontiguousarray(packed[:, D * m:].reshape(P, m, m))
+    low = ess < ess_threshold * P
     sampler = getattr(model._eng(), "mixture_sample", None)
     from ._abi import NGP_MAX_AUX
-    if sampler is not None and 0 < len(dates) <= NGP_MAX_AUX:   # the device sampler's limit
-        # every scenario at once: add_data! weight update, maybe_resample! (ancestors ~ w, weights
-        # -> ancestor counts / P), then ONE device call that draws from all D mixtures
-        logw = model.log_weights[None, :] + (out["logml_full"].T - out["logml_base"][None, :])
-        mx = logw.max(axis=1, keepdims=True)
-        w = np.exp(logw - mx)
-        w /= w.sum(axis=1, keepdims=True)
-        ess = 1.0 / np.sum(w * w, axis=1)
-        low = ess < ess_threshold * P
+    if sampler is not None and 0 < m <= NGP_MAX_AUX:   # the device sampler's limit
+        # maybe_resample! for every scenario (ancestors ~ w, weights -> ancestor counts / P),
+        # then ONE device call that draws from all D mixtures
         if low.any():
             w[low] = rng.multinomial(P, w[low]) / P
-        means = (out["mu"] - b) / s                                   # [P, D, m]
         seed = int(rng.integers(0, 2**63 - 1))
         smp, _, info = sampler(w, means, covs, int(draws), seed)      # [D, draws, m]
         bad = np.flatnonzero(info)
         if bad.size:
             raise autogp.PosDefException(int(info[bad[0]]), int(bad[0]))
-        res = smp.reshape(D * int(draws), len(dates)).T
+        res = smp.reshape(D * int(draws), m).T
         return _apply(inv_transformation, np.ascontiguousarray(res))
-    res = np.empty((len(dates), D * draws))
+    res = np.empty((m, D * draws))
     for sc in range(D):
-        logw = model.log_weights + (out["logml_full"][:, sc] - out["logml_base"])
-        from . import _lib
-        w, ess, _ = _lib.weights_normalize(logw)
-        if ess < ess_threshold * P:          # maybe_resample!: ancestors ~ w, weights -> uniform
-            anc = rng.choice(P, size=P, p=w)
-            w = np.bincount(anc, minlength=P) / P
-        mix = autogp.MixtureMVN((out["mu"][:, sc, :] - b) / s, covs, w, rng)
+        wsc = w[sc]
+        if low[sc]:          # maybe_resample!: ancestors ~ w, weights -> uniform
+            anc = rng.choice(P, size=P, p=wsc)
+            wsc = np.bincount(anc, minlength=P) / P
+        mix = autogp.MixtureMVN(means[:, sc, :], covs, wsc, rng)
         res[:, sc * draws:(sc + 1) * draws] = mix.rand(draws)
     return _apply(inv_transformation, res)

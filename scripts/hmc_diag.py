@@ -20,10 +20,10 @@ model._logml = lm.copy()
 print("initial logml: median %.1f best %.1f" % (np.median(lm), lm.max()))
 for eps in (0.005, 0.02, 0.05, 0.1):
     m2 = autogp.GPModel.from_dict(model.to_dict(), engine=eng)
-    accs = [autogp._hmc_move(m2, t, y, 10, eps) for _ in range(10)]
+    accs = [autogp._hmc_move([m2], t, [y], 10, eps) for _ in range(10)]
     print(f"eps={eps}: HMC acceptance per move {np.mean(accs)/64:.2f}; logml median {np.median(m2._logml):.1f} best {m2._logml.max():.1f}")
 m3 = autogp.GPModel.from_dict(model.to_dict(), engine=eng)
-acc = [autogp._structure_move(m3, t, y) for _ in range(20)]
+acc = [autogp._structure_move([m3], t, [y]) for _ in range(20)]
 print("structure move acceptance per move: %.3f" % (np.mean(acc) / 64), " logml median %.1f best %.1f" % (np.median(m3._logml), m3._logml.max()))
 # what does the truth score?
 truth = gp.Plus(gp.Linear(0.0, 0.1, 1.0), gp.Periodic(1.0, 52 / 155, 1.0))

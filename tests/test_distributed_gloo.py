@@ -124,6 +124,79 @@ def test_a_sharded_model_reproduces_the_single_rank_model():
     assert np.array_equal(np.concatenate([res[0]["lw"], res[1]["lw"]]), ref["lw"])
 
 
+def _fit_and_nowcast(P, seed):
+    """make_and_fit_model, then forecast_with_nowcasts in the shared-K mode and in two lockstep
+    refinement modes (one with every scenario resampling), on whatever process group there is."""
+    from nowcastautogp_amd import distributed as D
+    from nowcastautogp_amd import nowcast as nc
+    from tests import mirror_contracts as mc
+    from tests.engine_oracle import OracleEngine
+    calls = {"gather": 0, "objects": 0}
+    real_rows, real_many = D.all_gather_rows, D.exchange_particles_many
+
+    def rows(*a, **k):
+        calls["gather"] += 1
+        return real_rows(*a, **k)
+
+    def many(*a, **k):
+        calls["objects"] += 1
+        return real_many(*a, **k)
+
+    D.all_gather_rows, D.exchange_particles_many = rows, many
+    data = nc.create_transformed_data(mc.days(0, 20), mc.series20(), transformation=lambda v: v)
+    model = nc.make_and_fit_model(data, engine=OracleEngine(), seed=seed, n_particles=P, n_mcmc=1,
+                                  n_hmc=1)
+    scen = nc.create_nowcast_data([[101.0, 102.5], [99.0, 104.0], [103.0, 100.5]], mc.days(20, 22))
+    dates = mc.days(22, 25)
+    out = {}
+    for name, mode in (("shared_k", dict(ess_threshold=0.5)), ("hmc", dict(n_hmc=1)),
+                       ("structure_resampled", dict(n_mcmc=1, n_hmc=1, ess_threshold=1.0))):
+        calls["gather"] = calls["objects"] = 0
+        out[name] = nc.forecast_with_nowcasts(model, scen, dates, 4, **mode)
+        out[name + "_collectives"] = dict(calls)
+    D.all_gather_rows, D.exchange_particles_many = real_rows, real_many
+    return out
+
+
+def _worker_nowcast(rank, world, port, q, P, seed):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank, _fit_and_nowcast(P, seed)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_forecast_with_nowcasts_batches_scenarios_and_reproduces_one_rank():
+    """with the particles sharded over ranks forecast_with_nowcasts keeps
+    its batched forms — the shared-K call in the default mode, lockstep P x D calls in the
+    refinement modes — with ONE log-weight all-gather per weight update for ALL scenarios and ONE
+    descriptor exchange when scenarios resample; the draws are the single-rank draws."""
+    P, seed = 5, 4
+    ref = _fit_and_nowcast(P, seed)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_nowcast, args=(r, world, port, q, P, seed))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        for name in ("shared_k", "hmc", "structure_resampled"):
+            assert res[r][name].shape == (3, 12)
+            assert np.allclose(res[r][name], ref[name], rtol=1e-9, atol=1e-9), name
+        # collectives of one forecast over D = 3 scenarios: independent of D
+        assert res[r]["shared_k_collectives"] == {"gather": 2, "objects": 0}
+        # add_data (0) + maybe_resample (1) + predict (weights 1 + mixtures 1)
+        assert res[r]["hmc_collectives"] == {"gather": 3, "objects": 0}
+        assert res[r]["structure_resampled_collectives"] == {"gather": 3, "objects": 1}
+
+
 def test_shard_partition_covers_everything():
     from nowcastautogp_amd.distributed import shard
     for P in (1, 7, 64, 257):

@@ -224,3 +224,90 @@ def test_a_horizon_longer_than_one_call_is_served_in_pairs_of_blocks(eng):
     # so many appended points that no date fits beside them: a clear error
     with pytest.raises(ValueError, match="forecast horizon"):
         autogp.horizon_blocks(20, 171, 5)
+
+
+class _NoSharedK:
+    """OracleEngine without the shared-K ``nowcast`` entry point: add_data_lockstep then evaluates
+    P x D per-item logml's — the very calls the per-scenario loop makes, so results are identical."""
+
+    def __init__(self):
+        self._e = OracleEngine()
+        self.calls = []
+
+    def logml(self, programs, t, y):
+        self.calls.append(("logml", len(programs), np.ndim(y)))
+        return self._e.logml(programs, t, y)
+
+    def logml_grad(self, programs, t, y):
+        self.calls.append(("logml_grad", len(programs), np.ndim(y)))
+        return self._e.logml_grad(programs, t, y)
+
+    def predict(self, programs, t, y, t_new, noise_on_new=True):
+        self.calls.append(("predict", len(programs), np.ndim(y)))
+        return self._e.predict(programs, t, y, t_new, noise_on_new)
+
+
+LOCKSTEP_MODES = [dict(n_hmc=2), dict(n_mcmc=2, n_hmc=1), dict(forecast_n_hmc=1),
+                  dict(n_mcmc=1, n_hmc=1, ess_threshold=1.0, forecast_n_hmc=1),
+                  dict(ess_threshold=1.0, n_hmc=1)]
+
+
+@pytest.mark.parametrize("mode", LOCKSTEP_MODES, ids=lambda m: ",".join(f"{k}={v}" for k, v in m.items()))
+def test_lockstep_scenarios_equal_the_per_scenario_loop(mode):
+    """the refinement modes of forecast_with_nowcasts (reference
+    src/forecasting.jl:54-75, 131-159) advance their D scenario clones together — every proposal /
+    leapfrog / prediction ONE engine call of P x D items — and give what the reference's
+    per-scenario loop gives for the same seed."""
+    import copy
+    eng = _NoSharedK()
+    base = mc.fitted(eng, seed=31, n_particles=3)
+    snap = base.to_dict()
+    scen = nc.create_nowcast_data([[101.0, 102.5], [99.0, 104.0], [103.0, 100.5], [100.0, 100.0]],
+                                  mc.days(20, 22))
+    dates = mc.days(22, 26)
+    a_model = nc.GPModel.from_dict(copy.deepcopy(snap), engine=eng)
+    b_model = nc.GPModel.from_dict(copy.deepcopy(snap), engine=eng)
+    eng.calls.clear()
+    a = nc.forecast_with_nowcasts(a_model, scen, dates, 5, lockstep=True, **mode)
+    calls_lock = list(eng.calls)
+    eng.calls.clear()
+    b = nc.forecast_with_nowcasts(b_model, scen, dates, 5, lockstep=False, **mode)
+    calls_seq = list(eng.calls)
+    assert a.shape == b.shape == (4, 20)
+    assert np.array_equal(a, b)
+    # the lockstep run issues P x D-item gradient / predict calls with one y row per item; the
+    # loop issues D times as many P-item calls with a shared y
+    P, D = 3, 4
+    grads = [c for c in calls_lock if c[0] == "logml_grad"]
+    assert grads and all(c[1] == P * D and c[2] == 2 for c in grads)
+    assert all(c[1] == P * D for c in calls_lock if c[0] == "predict")
+    assert len([c for c in calls_seq if c[0] == "logml_grad"]) == D * len(grads)
+    assert all(c[1] == P and c[2] == 1 for c in calls_seq if c[0] == "logml_grad")
+
+
+def test_lockstep_with_the_shared_factor_weight_update(eng):
+    """With a shared-K entry point the D weight updates of add_data! come from ONE query of the
+    base model (P factorisations, not P x D); same draws as the loop up to rounding."""
+    import copy
+    base = mc.fitted(eng, seed=32, n_particles=3)
+    snap = base.to_dict()
+    scen = nc.create_nowcast_data([[101.0, 102.5], [99.0, 104.0], [103.0, 100.5]], mc.days(20, 22))
+    dates = mc.days(22, 25)
+    for mode in (dict(n_hmc=1), dict(forecast_n_hmc=1, ess_threshold=1.0)):
+        a = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=eng), scen,
+                                      dates, 4, lockstep=True, **mode)
+        b = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=eng), scen,
+                                      dates, 4, lockstep=False, **mode)
+        assert np.allclose(a, b, rtol=1e-7, atol=1e-7)
+
+
+def test_lockstep_models_must_share_their_dates(eng):
+    base = mc.fitted(eng, seed=33, n_particles=2)
+    other = mc.fitted(eng, seed=33, n_particles=2, dates=mc.days(1, 21))
+    with pytest.raises(ValueError, match="lockstep"):
+        autogp.mcmc_parameters_lockstep([base, other], 1)
+    # scenarios on different dates fall back to the per-scenario loop
+    ident = lambda v: v  # noqa: E731
+    scen = [nc.TData(mc.days(20, 22), [101.0, 102.0], transformation=ident),
+            nc.TData(mc.days(20, 21), [101.5], transformation=ident)]
+    assert nc.forecast_with_nowcasts(base, scen, mc.days(22, 24), 3, n_hmc=1).shape == (2, 6)
