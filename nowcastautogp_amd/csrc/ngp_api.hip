@@ -542,8 +542,9 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
         tm.run(fat ? (mixed ? 9 : 0) : 6, bc * fl, bc * by,
                [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, s, sp); });
         if (mixed && fat && order_buf && jj >= 8 && jj % MIXED_REORDER == 8) {
-            launch_mixed_order(p0, order_prev, order_buf, bc, s);
-            p0.order = order_buf;
+            // p0.order stays null (dispatch order) unless the ranking was really launched:
+            // order_buf comes from the caching allocator uninitialised
+            if (launch_mixed_order(p0, order_prev, order_buf, bc, s)) p0.order = order_buf;
         }
         if (ahead && jj > 0) {
             (void)hipEventRecord(ln.fork, s);
@@ -845,39 +846,51 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
         const size_t aux_bytes = sizeof(double) * (size_t)g.naux_pad * g.n0;
         size_t item_bytes = l_bytes + tab_bytes + sig_bytes + sizeof(double) * NB * NB;
         if (mixed)
-            item_bytes += l_bytes / 2 + 4 * nbt * g.nb0 + aux_bytes +
-                          (refine ? sizeof(double) * NB * NB * (size_t)g.nb0 + 2 * aux_bytes : 0);
+            item_bytes += l_bytes / 2 + 4 * nbt * g.nb0 + aux_bytes + 16 +
+                          (refine ? sizeof(double) * NB * NB * (size_t)g.nb0 + 2 * aux_bytes +
+                                        16 * (size_t)g.naux * g.naux + 8 * (size_t)g.naux + 20
+                                  : 0);
         // as few chunks as the memory allows, of equal size (a short last chunk runs every launch
         // of the sweep again for a fraction of the items)
         // (several kernels index the items of a chunk with blockIdx.y: at most 65,535 of them)
         const size_t bc_max = std::min<size_t>(
             std::min<size_t>((size_t)g.B, MAX_CHUNK_ITEMS), std::max<size_t>(1, c->mem_cap / item_bytes));
-        const size_t nchunks = ((size_t)g.B + bc_max - 1) / bc_max;
-        const int Bc = (int)(((size_t)g.B + nchunks - 1) / nchunks);
+        size_t nchunks = ((size_t)g.B + bc_max - 1) / bc_max;
+        int Bc = 0;
+        size_t mstep = 0;
+        ngp_status st = NGP_OK;
+        // the estimate above leaves the allocator's rounding and other live handles out: when an
+        // allocation fails the job is cut into more chunks instead of being refused
+        for (;; nchunks *= 2) {
+            Bc = (int)(((size_t)g.B + nchunks - 1) / nchunks);
+            // refinement sweeps need every block inverse M_j, not only the current one
+            mstep = refine ? (size_t)Bc * NB * NB : 0;
+            st = dalloc(&Lbuf, l_bytes * (size_t)Bc);
+            if (!st) st = dalloc(&dinv, sizeof(double) * (size_t)Bc * NB * NB * (refine ? g.nb0 : 1));
+            if (!st && g.lattice) st = dalloc(&tab, tab_bytes * (size_t)Bc);
+            if (!st && g.lattice) st = dalloc(&sig, sig_bytes * (size_t)Bc);
+            if (!st && mixed) {
+                st = dalloc(&L32, (l_bytes / 2) * (size_t)Bc);
+                if (!st) st = dalloc(&tmx, 4 * nbt * g.nb0 * (size_t)Bc);
+                if (!st) st = dalloc(&cnt, 8 * (size_t)Bc);
+                if (!st) st = dalloc(&order_buf, 4 * (size_t)Bc);
+                if (!st) st = dalloc(&order_prev, 4 * (size_t)Bc);
+                if (!st) st = dalloc((void **)&rb.X, aux_bytes * (size_t)Bc);
+            }
+            if (!st && refine) {
+                st = dalloc((void **)&rb.A, aux_bytes * (size_t)Bc);
+                if (!st) st = dalloc((void **)&rb.R, aux_bytes * (size_t)Bc);
+                if (!st) st = dalloc((void **)&rb.S, 8 * (size_t)g.naux * g.naux * Bc);
+                if (!st) st = dalloc((void **)&rb.T, 8 * (size_t)g.naux * g.naux * Bc);
+                if (!st) st = dalloc((void **)&rb.U, 8 * (size_t)g.naux * Bc);
+                if (!st) st = dalloc((void **)&rb.delta, 16 * (size_t)Bc);
+                if (!st) st = dalloc((void **)&rb.items, 4 * (size_t)Bc);
+            }
+            if (st != NGP_ERR_TOO_LARGE || Bc <= 1) break;
+            for (void *q : bufs) c->release(q);
+            bufs.clear();
+        }
         single_chunk = Bc >= g.B;
-        // refinement sweeps need every block inverse M_j, not only the current one
-        const size_t mstep = refine ? (size_t)Bc * NB * NB : 0;
-        ngp_status st = dalloc(&Lbuf, l_bytes * (size_t)Bc);
-        if (!st) st = dalloc(&dinv, sizeof(double) * (size_t)Bc * NB * NB * (refine ? g.nb0 : 1));
-        if (!st && g.lattice) st = dalloc(&tab, tab_bytes * (size_t)Bc);
-        if (!st && g.lattice) st = dalloc(&sig, sig_bytes * (size_t)Bc);
-        if (!st && mixed) {
-            st = dalloc(&L32, (l_bytes / 2) * (size_t)Bc);
-            if (!st) st = dalloc(&tmx, 4 * nbt * g.nb0 * (size_t)Bc);
-            if (!st) st = dalloc(&cnt, 8 * (size_t)Bc);
-            if (!st) st = dalloc(&order_buf, 4 * (size_t)Bc);
-            if (!st) st = dalloc(&order_prev, 4 * (size_t)Bc);
-            if (!st) st = dalloc((void **)&rb.X, aux_bytes * (size_t)Bc);
-        }
-        if (!st && refine) {
-            st = dalloc((void **)&rb.A, aux_bytes * (size_t)Bc);
-            if (!st) st = dalloc((void **)&rb.R, aux_bytes * (size_t)Bc);
-            if (!st) st = dalloc((void **)&rb.S, 8 * (size_t)g.naux * g.naux * Bc);
-            if (!st) st = dalloc((void **)&rb.T, 8 * (size_t)g.naux * g.naux * Bc);
-            if (!st) st = dalloc((void **)&rb.U, 8 * (size_t)g.naux * Bc);
-            if (!st) st = dalloc((void **)&rb.delta, 16 * (size_t)Bc);
-            if (!st) st = dalloc((void **)&rb.items, 4 * (size_t)Bc);
-        }
         if (st) return st;
         const Lane ln = lane_of(c);
         const double nrows_aux = (double)g.naux;

@@ -159,7 +159,8 @@ void launch_refine_gram(const JobGeom &g, const double *A, const double *X, cons
 void launch_mfma_f32_probe(const float *A, const float *Bm, float *Dout, hipStream_t s);
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 // order <- items by fp64 tile products since the last call, most first (prev: [Bc] snapshot)
-void launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int Bc, hipStream_t s);
+constexpr int NGP_MIXED_ORDER_MAX = 8192;   // items mixed_order_kernel ranks in LDS (32 KiB)
+bool launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int Bc, hipStream_t s);
 void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
                       int Bc, hipStream_t s);

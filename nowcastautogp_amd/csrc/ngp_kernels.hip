@@ -2510,19 +2510,30 @@ __global__ __launch_bounds__(256) void refine_gram_final_kernel(JobGeom g, const
         const double gaa = Si[a * na + a], gbb = Si[b * na + b];
         const double den = sqrt(fabs(gaa * gbb));
         const double tv = 0.5 * fabs(Ti[a * na + b] + Ti[b * na + a]);
-        if (den > 0.0) dm = fmax(dm, tv / den);
-        else if (tv > 0.0) dm = INFINITY;
+        // fmax drops NaN: a non-finite correction must come out as NaN (the item is then
+        // never marked refined), so it is carried explicitly
+        if (!(tv == tv) || !(den == den)) dm = NAN;
+        else if (dm == dm) {
+            if (den > 0.0) dm = fmax(dm, tv / den);
+            else if (tv > 0.0) dm = INFINITY;
+        }
     }
     red[tid] = dm;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) red[tid] = fmax(red[tid], red[tid + off]);
+        if (tid < off) {
+            const double a = red[tid], b = red[tid + off];
+            red[tid] = (a == a && b == b) ? fmax(a, b) : NAN;
+        }
         __syncthreads();
     }
     if (tid == 0) {
         delta[2 * item] = red[0];
         double rho2 = 0.0;
-        for (int a = 0; a < na; ++a) rho2 = fmax(rho2, U[(long)item * na + a]);
+        for (int a = 0; a < na; ++a) {
+            const double u = U[(long)item * na + a];
+            rho2 = (u == u && rho2 == rho2) ? fmax(rho2, u) : NAN;
+        }
         delta[2 * item + 1] = sqrt(rho2);
     }
 }
@@ -3576,9 +3587,15 @@ void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipS
     hipLaunchKernelGGL(aux_update_kernel, dim3((n + 3) / 4, Bc), dim3(256), 0, s, g, p, j);
 }
 
-void launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int Bc, hipStream_t s) {
+bool launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int Bc, hipStream_t s) {
+    // one workgroup ranks the chunk in LDS (4 B per item): chunks beyond NGP_MIXED_ORDER_MAX items
+    // keep their dispatch order — with that many items a launch no longer ends on a few heavy
+    // ones.  Returns whether `order` may be used (the launch was accepted).
+    if (Bc > NGP_MIXED_ORDER_MAX) return false;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(mixed_order_kernel, dim3(1), dim3(256), sizeof(unsigned) * (size_t)Bc, s,
                        (const unsigned *)p.mixcnt, prev, order, Bc);
+    return hipGetLastError() == hipSuccess;
 }
 
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {

@@ -180,6 +180,18 @@ def model_from_wire(model, d: Dict[str, Any]) -> None:
     model._perm = np.array(d["perm"], dtype=np.int64)
     model._logml = np.array(d["logml"], dtype=np.float64)
     model.wire_spec = dict(d["spec"])
+    # the cached per-particle logml belongs to the formula variants / jitter it was computed under:
+    # under another spec the next weight update (logml(n+d) - logml(n)) would mix two
+    # parametrisations, so a snapshot is only loaded under the spec that wrote it
+    eng = getattr(model, "engine", None)
+    if eng is not None and hasattr(eng, "ctx") and d["spec"] is not None:
+        sp = eng.ctx.get_spec()
+        have = dict(se_form=int(sp.se_form), periodic_form=int(sp.periodic_form),
+                    cp_form=int(sp.cp_form), jitter=float(sp.jitter))
+        want = {k: d["spec"].get(k) for k in have}
+        if any(want[k] is not None and want[k] != have[k] for k in have):
+            raise ValueError(f"ngp-model dict was written under spec {want}, the engine runs {have}: "
+                             "load it with an engine of the same spec (ngp_set_spec)")
     rng = d.get("rng")
     if rng and rng.get("kind") == "numpy-pcg64" and len(rng["particles"]) == len(model.particles):
         model._root, model._gen = int(rng["root"]), int(rng["generation"])

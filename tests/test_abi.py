@@ -74,6 +74,22 @@ def test_weights_normalize_host(lib):
     assert np.array_equal(w, w2) and ess == ess2 and ln == ln2
 
 
+def test_weights_normalize_cols_equals_the_column_by_column_call(lib):
+    """ngp_weights_normalize_cols: the D scenario clones' weight vectors in one call (columns of
+    the all-gathered [P, D] matrix), dead particles (-inf / NaN) included."""
+    rng = np.random.default_rng(8)
+    lw = -700.0 + 4.0 * rng.standard_normal((9, 5))
+    lw[2, 1], lw[4, 3], lw[:, 4] = -np.inf, np.nan, -np.inf      # column 4: nobody alive
+    w, ess, ln = _lib.weights_normalize_cols(lw)
+    for s in range(lw.shape[1]):
+        w1, e1, l1 = _lib.weights_normalize(np.ascontiguousarray(lw[:, s]))
+        assert np.array_equal(w[:, s], w1, equal_nan=True)
+        assert (ess[s] == e1 or (np.isnan(ess[s]) and np.isnan(e1))) and ln[s] == l1
+    assert w[2, 1] == 0.0 and w[4, 3] == 0.0 and np.isnan(w[:, 4]).all()
+    w_ref, ess_ref, _ = oracle_c.weights_normalize(np.ascontiguousarray(lw[:, 0]))
+    assert np.array_equal(w[:, 0], w_ref) and ess[0] == ess_ref
+
+
 def test_context_fails_loudly_without_a_gpu(lib):
     import torch
     if torch.cuda.is_available():

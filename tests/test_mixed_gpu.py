@@ -189,3 +189,25 @@ def test_mixed_on_irregular_times(ctx):
         assert nerr(np.diag(mix["sigma"][b]), np.diag(ref64["sigma"][b])) < TOL_MIXED
     mu, sg, lm, info = oracle_np.predict(w.programs[2], t, w.y, t_new)
     assert info == 0 and nerr(mix["logml_full"][2, 0], lm) < TOL_MIXED and nerr(mix["mu"][2, 0], mu) < TOL_MIXED
+
+
+def test_mixed_large_chunk_keeps_dispatch_order_and_matches_fp64(ctx):
+    """a mixed chunk of more items than mixed_order_kernel can rank in LDS
+    (NGP_MIXED_ORDER_MAX = 8192) used to launch it with too much dynamic LDS, unchecked, and then
+    dispatch through an uninitialised order buffer.  9,000 items at n = 705 (11 block columns, past
+    the first re-ranking point) now run in dispatch order: every item against the fp64 path."""
+    from nowcastautogp_amd.synthetic import jitter_programs
+    w = make_workload("C5", n=704, P=30)
+    progs = jitter_programs(w.programs, 300, np.random.default_rng(17))
+    assert len(progs) == 9000
+    tt = np.concatenate([w.t, w.t_add])
+    yy = np.concatenate([w.y, w.y_add[0]])
+    ref64 = _run(ctx, default_spec(), progs, tt, yy, w.t_new)
+    mix = _run(ctx, default_spec(NGP_PREC_MIXED), progs, tt, yy, w.t_new)
+    assert not ref64["info"].any() and not mix["info"].any()
+    assert (mix["frac_f32"] > 0).any()
+    assert nerr(mix["logml_full"], ref64["logml_full"]) < TOL_MIXED
+    worst = max(nerr(mix["mu"][b], ref64["mu"][b]) for b in range(len(progs)))
+    assert worst < TOL_MIXED, worst
+    for b in range(0, len(progs), 50):
+        assert nerr(np.diag(mix["sigma"][b]), np.diag(ref64["sigma"][b])) < TOL_MIXED

@@ -47,3 +47,32 @@ def test_a_dict_without_rng_state_is_reseeded_not_refused():
     model = nc.GPModel(d, engine=OracleEngine())
     assert len(model.prng) == len(model.particles)
     assert autogp.predict_mvn(model, mc.days(20, 22)).rand(3).shape == (2, 3)
+
+
+def test_a_dict_written_under_another_spec_is_refused():
+    """the cached per-particle logml of a snapshot belongs to the formula variants and
+    jitter it was computed under; loading it under an engine with another spec would mix two
+    parametrisations in the next weight update."""
+    from nowcastautogp_amd._abi import NgpSpec
+
+    class Ctx:
+        def __init__(self, spec):
+            self._s = spec
+
+        def get_spec(self):
+            return self._s
+
+    class Eng(OracleEngine):
+        def __init__(self, spec):
+            super().__init__()
+            self.ctx = Ctx(spec)
+
+    with open(GOLDEN) as f:
+        d = json.load(f)["model"]
+    same = NgpSpec(int(d["spec"]["se_form"]), int(d["spec"]["periodic_form"]),
+                   int(d["spec"]["cp_form"]), 0, float(d["spec"]["jitter"]))
+    assert nc.GPModel(copy.deepcopy(d), engine=Eng(same)).to_dict()["spec"] == d["spec"]
+    for other in (NgpSpec(1 - same.se_form, same.periodic_form, same.cp_form, 0, same.jitter),
+                  NgpSpec(same.se_form, same.periodic_form, same.cp_form, 0, 10 * same.jitter)):
+        with pytest.raises(ValueError, match="spec"):
+            nc.GPModel(copy.deepcopy(d), engine=Eng(other))
