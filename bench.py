@@ -2,9 +2,12 @@
 """bench.py — the hot path on BASELINE.json's configurations.
 
     --config C3 (default, the headline)   n = 2048 (+1), 64 particles x 200 nowcast scenarios, fp64
-    --config C4                           n = 2048 (+1), 256 particles x 200 scenarios SHARDED over
-                                          the ranks (32 particles per GPU at 8), resample exchange
-                                          inside the step
+    --config C4                           n = 2048 (+1), ONE model of 256 particles SHARDED over the
+                                          ranks (32 per GPU at 8) x 200 scenarios; a step is the
+                                          PRODUCT's forecast_with_nowcasts in a refinement mode
+                                          (lockstep P_local x D calls, weight all-gather + resample
+                                          exchange inside)
+    --mode grad                           the logml + gradient path (HMC leapfrogs) on the C3 items
     --config C5                           n = 8192 (+1), 64 particles, mixed precision (fp32 matrix
                                           cores where provably harmless + fp64 Gram refinement);
                                           the fp64 path is timed beside it
@@ -40,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense fp64 matrix (not in the local guide)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PMC_DIR = os.path.join(ROOT, "profiles", "r02")
+PMC_DIRS = [os.path.join(ROOT, "profiles", r) for r in ("r03", "r02")]   # newest first
 
 
 def F_logml(n):
@@ -48,12 +51,29 @@ def F_logml(n):
     return n ** 3 / 3.0 + 2.0 * n ** 2
 
 
+def F_logml_grad(n):
+    """... of one logml + gradient evaluation: the factorisation, K^-1 from
+    it (W = L^-T by a block-triangular solve, n^3/3, and the Gram product W W', n^3/3 — together
+    what dpotri's 2 n^3 / 3 costs), the solves; the O(n^2 |tree|) contraction is not counted."""
+    return n ** 3 + 2.0 * n ** 2
+
+
+KERNEL_OF_CLASS = {
+    "chol_col": "chol_col_glds_kernel<false>", "chol_col_mixed": "chol_col_glds_kernel<true>",
+    "chol_col_thin": "chol_col_thin_kernel / chol_col_kernel", "chol_diag": "chol_diag_kernel",
+    "fill": "tables_kernel + fill_*_kernel", "grad_kinv": "grad_kinv_lds_kernel",
+    "grad_contract": "grad_alpha / grad_contract_lattice / grad_reduce kernels",
+    "gram": "gram_kernel", "epilogue": "epilogue_kernel", "aux_update": "aux_update_kernel",
+    "diag_ahead": "diag_ahead_kernel", "refine": "Gram refinement kernels"}
+
+
 def measured_traffic(config, kernel_key, items_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS build
     (scripts/gpu_pmc.sh -> profiles/r02/pmc_<config>.json; FETCH_SIZE doubled per the guide's
     gfx950 correction, WRITE_SIZE as is).  None if the file is absent: no literals."""
-    path = os.path.join(PMC_DIR, f"pmc_{config}.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(d_, f"pmc_{config}.json") for d_ in PMC_DIRS)
+                 if os.path.exists(q)), None)
+    if path is None:
         return None, None
     with open(path) as f:
         d = json.load(f)
@@ -85,6 +105,8 @@ def cpu_baseline(config, rank, args, idx, gpu_logml):
     for flag, v in (("--n", args.n), ("--particles", args.particles), ("--scenarios", args.scenarios)):
         if v is not None:
             cmd += [flag, str(v)]
+    if args.mode == "grad":
+        cmd.append("--with-grad")
     t0 = time.perf_counter()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     if out.returncode != 0:
@@ -92,10 +114,14 @@ def cpu_baseline(config, rank, args, idx, gpu_logml):
     r = json.loads(out.stdout.strip().splitlines()[-1])
     ref = np.array(r["logml"])
     err = float(np.max(np.abs(gpu_logml[np.array(r["items"])] - ref) / np.abs(ref)))
-    return {"value": r["items_per_s"], "unit": "particle-logml/s", "cores": r["workers"],
+    return {"value": r["items_per_s"],
+            "unit": "particle-logml+gradient/s" if args.mode == "grad" else "particle-logml/s",
+            "cores": r["workers"],
             "kind": "port",
             "sample": f"{len(idx)} of the items (numpy/scipy OpenBLAS oracle: covariance assembly + "
-                      f"dpotrf + solves), {r['workers']} worker processes x 1 BLAS thread on "
+                      + ("dpotrf + dpotri + reverse-mode sweep of the kernel tree"
+                         if args.mode == "grad" else "dpotrf + solves")
+                      + f"), {r['workers']} worker processes x 1 BLAS thread on "
                       f"{r['usable_cores']} usable of {r['host_cores']} host cores"
                       + (f" (cgroup quota {r['cgroup_cpu_quota']:g})" if r.get("cgroup_cpu_quota") else "")
                       + f", {r['wall_s']:.1f} s wall ({time.perf_counter() - t0:.1f} s "
@@ -130,91 +156,201 @@ class TracingEngine:
         self._note("logml_grad", len(t), ka.n)
         return self._e.logml_grad_flat(ka, t, y)
 
+    def predict(self, programs, t, y, t_new, noise_on_new=True):
+        self._note("predict", len(t), len(programs))
+        return self._e.predict(programs, t, y, t_new, noise_on_new)
+
+    def snapshot(self):
+        """{"kind@n": {"calls", "items", "max_items_per_call"}} and a reset"""
+        out = {f"{k[0]}@{k[1]}": {"calls": v[0], "items": v[1]} for k, v in sorted(self.trace.items())}
+        raw, self.trace = self.trace, {}
+        return out, raw
+
     def __getattr__(self, name):
         return getattr(self._e, name)
 
 
+def cpu_prices(config, rank, sizes):
+    """Seconds per logml and per logml + gradient evaluation of the CPU oracle at every size in
+    ``sizes`` (one BLAS thread, measured now on this host by oracle/cpu_baseline.py in a child
+    process): the prices the call traces below are multiplied with."""
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--config", config,
+           "--rank", str(rank), "--sizes", ",".join(str(s) for s in sizes), "--per-size", "2",
+           "--with-grad", "--workers", "0", "--max-workers", str(max(1, 2 * len(sizes)))]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+    if out.returncode != 0:
+        return None, out.stderr[-300:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    return (r["logml_s_per_item_by_n"], r["logml_grad_s_per_item_by_n"]), None
+
+
+def cpu_estimate(raw_trace, prices, cores, parallel_units, what):
+    """CPU core-seconds and wall-clock of a call trace {(kind, n): [calls, items]}: items x the
+    measured price of that evaluation at that size; predict is priced as a logml (its solves are
+    O(n^2 m))."""
+    per, perg = prices
+    core_s = 0.0
+    for (kind, ns), (calls, items) in raw_trace.items():
+        core_s += items * (perg[str(ns)] if kind == "logml_grad" else per[str(ns)])
+    use = max(1, min(cores, parallel_units))
+    return {"core_seconds": core_s, "wall_s_on_usable_cores": core_s / use, "cores_used": use,
+            "parallelism": what}
+
+
 def fit_forecast_wallclock(w, device, rank, args):
-    """End-to-end wall-clock of the two reference call sites through the host mirror and the HIP
-    engine: make_and_fit_model (SMC over data-annealing steps, structure MH + HMC rejuvenation)
-    then forecast_with_nowcasts over all scenarios (reference src/make_and_fit_model.jl:78-93,
-    src/forecasting.jl:117-167), with a CPU figure beside it: the fit's own call trace (how many
-    logml / logml+gradient evaluations at which size) priced with the CPU oracle's measured time
-    per logml at those sizes."""
+    """BASELINE metric (i): end-to-end wall-clock of the two reference call sites through the host
+    mirror and the HIP engine — make_and_fit_model (SMC over data-annealing steps, structure MH +
+    HMC rejuvenation) and forecast_with_nowcasts over all scenarios (reference
+    src/make_and_fit_model.jl:78-93, src/forecasting.jl:117-167) — each with a CPU figure beside
+    it: the leg's own call trace (how many logml / logml+gradient / predict evaluations at which
+    size) priced with the CPU oracle's time per evaluation at those sizes, measured in this run
+    (logml: covariance + dpotrf + solve; logml+gradient: + dpotri + one reverse sweep of the tree).
+    The reference itself (Julia + AutoGP.jl) cannot run here; the figure is an estimate of a CPU
+    port and is labelled so."""
     import datetime as dt
 
     from nowcastautogp_amd import autogp
     from nowcastautogp_amd import nowcast as nc
+    from nowcastautogp_amd.synthetic import make_workload
+    from oracle.cpu_baseline import usable_cores      # CPU-baseline leg only
     n, D, d, m = w.n, w.y_add.shape[0], w.t_add.size, w.t_new.size
     P = len(w.programs)
     d0 = dt.date(2000, 1, 2)
     dates = [d0 + dt.timedelta(weeks=i) for i in range(n + d + m)]
     data = nc.create_transformed_data(dates[:n], w.y, transformation=float)
     eng = TracingEngine(autogp.HipEngine(device))
-    settings = dict(n_particles=P, smc_data_proportion=0.1, n_mcmc=2, n_hmc=2,
-                    hmc_config={"n_leapfrog": 5, "eps": 0.01})
-    t0 = time.perf_counter()
-    model = nc.make_and_fit_model(data, engine=eng, seed=7, **settings)
-    t_fit = time.perf_counter() - t0
-    trace = {f"{k[0]}@{k[1]}": {"calls": v[0], "items": v[1]} for k, v in sorted(eng.trace.items())}
+    legs, raws = {}, {}
+
+    def timed(name, fn, **extra):
+        eng.snapshot()
+        t0 = time.perf_counter()
+        r = fn()
+        wall = time.perf_counter() - t0
+        trace, raw = eng.snapshot()
+        legs[name] = {"gpu_s": wall, "call_trace": trace, **extra}
+        raws[name] = raw
+        return r
+
+    # ---- the fit: a small sampler budget (as in rounds 1-2) and a mid one ----
+    small = dict(n_particles=P, smc_data_proportion=0.1, n_mcmc=2, n_hmc=2,
+                 hmc_config={"n_leapfrog": 5, "eps": 0.01})
+    model = timed("fit_small_budget", lambda: nc.make_and_fit_model(data, engine=eng, seed=7, **small),
+                  settings=small)
+    if not args.no_mid_fit:
+        nm, nh = (int(v) for v in args.mid_budget.split(","))
+        mid = dict(n_particles=P, smc_data_proportion=0.1, n_mcmc=nm, n_hmc=nh)
+        timed("fit_mid_budget", lambda: nc.make_and_fit_model(data, engine=eng, seed=8, **mid),
+              settings={**mid, "hmc_config": dict(autogp.DEFAULT_HMC)})
+    # ---- forecast_with_nowcasts: default mode (shared K, resident factor) ----
     scen = nc.create_nowcast_data([row for row in w.y_add], dates[n:n + d])
-    t0 = time.perf_counter()
-    fc = nc.forecast_with_nowcasts(model, scen, dates[n + d:], 20)
-    t_fc = time.perf_counter() - t0     # first call: factorises the fitted ensemble once
+    fdates = dates[n + d:]
+    fc = timed("forecast_with_nowcasts_first", lambda: nc.forecast_with_nowcasts(model, scen, fdates, 20))
     t0 = time.perf_counter()
     for _ in range(3):
-        fc = nc.forecast_with_nowcasts(model, scen, dates[n + d:], 20)
+        fc = nc.forecast_with_nowcasts(model, scen, fdates, 20)
     t_fc_again = (time.perf_counter() - t0) / 3   # factor resident, device mixture sampler
+    eng.snapshot()
     ok = bool(np.isfinite(fc).all()) and fc.shape == (m, D * 20)
-    res = {"fit_s": t_fit, "forecast_with_nowcasts_s": t_fc,
-           "forecast_with_nowcasts_again_s": t_fc_again, "n": n, "particles": P,
-           "scenarios": D, "draws_per_scenario": 20, "settings": settings,
-           "finite_and_shaped": ok, "fit_call_trace": trace}
-    # ---- CPU estimate of the same fit ----
-    sizes = sorted({k[1] for k in eng.trace})
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--config", args.config,
-           "--rank", str(rank), "--sizes", ",".join(str(s) for s in sizes), "--per-size", "2",
-           "--workers", "0", "--max-workers", str(max(1, len(sizes)))]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    if out.returncode == 0:
-        per = json.loads(out.stdout.strip().splitlines()[-1])["logml_s_per_item_by_n"]
-        from oracle.cpu_baseline import usable_cores      # CPU-baseline leg only
-        cores = usable_cores()[0]
-        GRAD_FACTOR = 3.0
-        cpu_core_s = 0.0
-        for (kind, ns), (calls, items) in eng.trace.items():
-            cpu_core_s += items * per[str(ns)] * (GRAD_FACTOR if kind == "logml_grad" else 1.0)
-        res["cpu_estimate"] = {
-            "fit_core_seconds": cpu_core_s,
-            "fit_s_on_all_cores": cpu_core_s / min(cores, P),
-            "cores_usable": min(cores, P),
-            "method": "sum over the GPU fit's call trace of items x (CPU oracle seconds per logml at "
-                      "that size, measured in this run, 1 BLAS thread) x (1 for logml, "
-                      f"{GRAD_FACTOR:g} for logml+gradient: reverse-mode differentiation through the "
-                      "Cholesky costs about three evaluations); parallel over particles only, as "
-                      "the reference is (Threads.@threads over particles inside AutoGP), so at most "
-                      "n_particles cores help",
-            "cpu_logml_s_per_item_by_n": per,
-        }
-        res["fit_speedup_vs_cpu_estimate"] = res["cpu_estimate"]["fit_s_on_all_cores"] / t_fit
-    else:
-        res["cpu_estimate"] = {"error": out.stderr[-300:]}
+    # ---- forecast_with_nowcasts with HMC refinement after every nowcast (src/forecasting.jl:147-148):
+    #      the D scenario clones advance in lockstep, every leapfrog ONE call of P x D items ----
+    hmc = {"n_leapfrog": args.hmc_leapfrog, "eps": 0.01}
+    fh = timed("forecast_with_nowcasts_hmc",
+               lambda: nc.forecast_with_nowcasts(model, scen, fdates, 20, n_hmc=2, hmc_config=hmc),
+               settings={"n_hmc": 2, "hmc_config": hmc, "scenarios": D, "particles": P,
+                         "draws_per_scenario": 20})
+    ok_h = bool(np.isfinite(fh).all()) and fh.shape == (m, D * 20)
+    grad_calls = [v for k, v in legs["forecast_with_nowcasts_hmc"]["call_trace"].items()
+                  if k.startswith("logml_grad@")]
+    legs["forecast_with_nowcasts_hmc"]["items_per_gradient_call"] = (
+        grad_calls[0]["items"] // grad_calls[0]["calls"] if grad_calls else 0)
+    legs["forecast_with_nowcasts_hmc"]["finite_and_shaped"] = ok_h
     # ---- one fit at a vignette-scale sampler budget (reference docs/vignettes/getting-started.jl:266-268:
     #      24 particles, n_mcmc 50-200, n_hmc 20-50 on a weekly series of a few hundred points) ----
     if not args.no_vignette_fit:
         nv = 208
-        from nowcastautogp_amd.synthetic import make_workload
         wv = make_workload("C2", n=nv, P=24, D=1)
         datav = nc.create_transformed_data(dates[:nv], wv.y, transformation=float)
         vs = dict(n_particles=24, smc_data_proportion=0.1, n_mcmc=50, n_hmc=20)
-        ev = TracingEngine(autogp.HipEngine(device))
-        t0 = time.perf_counter()
-        nc.make_and_fit_model(datav, engine=ev, seed=11, **vs)
-        res["vignette_scale_fit"] = {
-            "fit_s": time.perf_counter() - t0, "n": nv, "settings": vs,
-            "path_calls": sum(v[0] for v in ev.trace.values()),
-            "path_items": sum(v[1] for v in ev.trace.values())}
+        timed("vignette_scale_fit", lambda: nc.make_and_fit_model(datav, engine=eng, seed=11, **vs),
+              settings={**vs, "n": nv, "hmc_config": dict(autogp.DEFAULT_HMC)})
+    # ---- CPU prices at every size any leg touched, then every leg's estimate ----
+    sizes = sorted({k[1] for raw in raws.values() for k in raw})
+    prices, err = cpu_prices(args.config, rank, sizes)
+    cores = usable_cores()[0]
+    res = {"n": n, "particles": P, "scenarios": D, "draws_per_scenario": 20,
+           "fit_s": legs["fit_small_budget"]["gpu_s"],
+           "forecast_with_nowcasts_s": legs["forecast_with_nowcasts_first"]["gpu_s"],
+           "forecast_with_nowcasts_again_s": t_fc_again, "finite_and_shaped": ok, "legs": legs}
+    if prices is None:
+        res["cpu_estimate_error"] = err
+        return res
+    for name, leg in legs.items():
+        fan_out = name.startswith("forecast_with_nowcasts")
+        pv = 24 if name == "vignette_scale_fit" else P
+        leg["cpu_estimate"] = cpu_estimate(
+            raws[name], prices, cores, pv * D if fan_out else pv,
+            "one task per scenario x threads over particles (src/forecasting.jl:131-132)" if fan_out
+            else "threads over particles only, as AutoGP's fit is: at most n_particles cores help")
+        leg["speedup_vs_cpu_estimate"] = leg["cpu_estimate"]["wall_s_on_usable_cores"] / leg["gpu_s"]
+        if fan_out and name == "forecast_with_nowcasts_first":
+            # the reference refactorises every (particle, scenario) at add_data! and again in
+            # predict_mvn (2 P D evaluations at n + d); this library does P (or none, resident)
+            ref_core = 2 * P * D * prices[0][str(max(int(k) for k in prices[0]))]
+            leg["cpu_estimate_reference_algorithm"] = {
+                "core_seconds": ref_core, "wall_s_on_usable_cores": ref_core / min(cores, P * D)}
+    res["cpu_estimate_method"] = (
+        "per leg: sum over the GPU run's own call trace of items x the CPU oracle's seconds per "
+        "evaluation at that size (numpy + OpenBLAS, 1 BLAS thread, measured in this run: logml = "
+        "covariance + dpotrf + solve; logml+gradient = + dpotri + one reverse-mode sweep of the "
+        "kernel tree), divided by the cores the reference's parallelism can use on this host")
+    res["cpu_logml_s_per_item_by_n"] = prices[0]
+    res["cpu_logml_grad_s_per_item_by_n"] = prices[1]
+    res["cpu_grad_over_logml_factor_by_n"] = {k: prices[1][k] / prices[0][k] for k in prices[0]}
+    res["cpu_estimate"] = {"fit_s_on_all_cores": legs["fit_small_budget"]["cpu_estimate"]["wall_s_on_usable_cores"],
+                           "cores_usable": legs["fit_small_budget"]["cpu_estimate"]["cores_used"]}
+    res["fit_speedup_vs_cpu_estimate"] = legs["fit_small_budget"]["speedup_vs_cpu_estimate"]
     return res
+
+
+def other_configs(args):
+    """BASELINE configs C5 and C4 in the driver's record: compact legs run as child processes of
+    the default ``bench.py --gpus 1`` (a few seconds of GPU time each).
+    C5: n = 8192, 64 particles, mixed precision, 3 steps, the fp64 path beside it.
+    C4: ONE rank's share of the 8-GPU configuration (32 of the 256 particles x 200 scenarios)
+    through the product's forecast_with_nowcasts — the per-GPU step an 8-GPU run would take, without
+    its collectives' wire time."""
+    out = {}
+    legs = {"C5_mixed": ["--config", "C5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                         "--no-fit"],
+            "C4_one_rank_share": ["--config", "C4", "--particles", "32", "--steps", "1", "--warmup",
+                                  "1", "--headline-only"]}
+    for name, extra in legs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "timeout"}
+            continue
+        if r.returncode != 0:
+            out[name] = {"error": r.stderr[-300:]}
+            continue
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        c = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+             "steps": d["steps"], "workload": d["config"]["workload"],
+             "roofline_kernel_class": d["roofline"]["timing_class"],
+             "roofline_frac": d["roofline"]["frac"], "roofline_achieved": d["roofline"]["achieved"],
+             "roofline_peak": d["roofline"]["peak"], "kernels_ms_per_step": d["kernels_ms_per_step"],
+             "failed_items": d["failed_items"], "wall_s_with_startup": time.perf_counter() - t0}
+        if "mixed_precision" in d:
+            mp_ = d["mixed_precision"]
+            c.update(fp64_path_ms_per_step=mp_["fp64_path_ms_per_step"],
+                     speedup_vs_fp64_path=mp_["speedup_vs_fp64_path"],
+                     max_rel_logml_diff_vs_fp64_path=mp_.get("max_rel_logml_diff_vs_fp64_path"),
+                     refine_steps_histogram=mp_["refine_steps_histogram"],
+                     frac_of_blended_peak=d["roofline"].get("frac_of_blended_peak"))
+        out[name] = c
+    return out
 
 
 def main():
@@ -232,6 +368,15 @@ def main():
     ap.add_argument("--no-fit", action="store_true",
                     help="skip the end-to-end make_and_fit_model + forecast_with_nowcasts timing")
     ap.add_argument("--no-vignette-fit", action="store_true")
+    ap.add_argument("--no-mid-fit", action="store_true")
+    ap.add_argument("--mid-budget", default="5,5",
+                    help="n_mcmc,n_hmc of the mid-budget headline fit (default leapfrogs)")
+    ap.add_argument("--hmc-leapfrog", type=int, default=3,
+                    help="leapfrogs per HMC move in the forecast_with_nowcasts_hmc leg")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the compact C5 / C4-share legs of the default run")
+    ap.add_argument("--mode", default="predict", choices=["predict", "grad"],
+                    help="grad: a step is one logml + gradient call over the items (HMC leapfrog)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items in the CPU sample (0: auto)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps: no shared-K / resident-factor / fit / CPU legs, so a "
@@ -273,50 +418,77 @@ def main():
     from nowcastautogp_amd.synthetic import bench_items, jitter_programs, make_workload
 
     sharded = args.config == "C4"
+    grad_mode = args.mode == "grad"
     dev = torch.device("cuda", local_rank)
+    ctx = _lib.Context(local_rank)
+    job = ka = None
+    evals_per_item = 1
     if sharded:
-        # ONE ensemble of 256 particles for the whole job; particles dealt to the ranks by tree
-        # size, round-robin; every rank sees all 200 scenarios
+        # ONE model of 256 particles for the whole job, its particles sharded over the ranks
+        # (SURVEY.md section 8e).  A step is the PRODUCT's forecast_with_nowcasts in the HMC
+        # refinement mode (reference src/forecasting.jl:131-159 with n_hmc > 0): add_data! for
+        # all scenarios from the resident factor, ONE [P_local, D] log-weight all-gather,
+        # resampling of every scenario (ess_threshold = 1) with ONE descriptor exchange, then the
+        # lockstep HMC move (leapfrog + 1 gradient calls of P_local x D items) and the
+        # P_local x D predictive call, the mixture all-gather and the draws.
+        import datetime as dt
+
+        from nowcastautogp_amd import autogp, gp
+        from nowcastautogp_amd import nowcast as nc
         w = make_workload("C4", n=args.n, P=args.particles, D=args.scenarios)
         P_total = len(w.programs)
-        mine = distributed.deal_round_robin([len(p[0]) for p in w.programs], world)[rank]
+        # particle order: dealt round-robin by tree size, so the block partition is balanced
+        deal = distributed.deal_round_robin([len(p[0]) for p in w.programs], world)
+        order = np.concatenate(deal)
         D, n, d, m = w.y_add.shape[0], w.n, w.t_add.size, w.t_new.size
-        rng = np.random.Generator(np.random.PCG64(99))
-        allprogs = jitter_programs(w.programs, D, rng)        # same on every rank: item = p * D + s
-        progs = [allprogs[p * D + s] for p in mine for s in range(D)]
+        dates = [dt.date(2000, 1, 2) + dt.timedelta(weeks=i) for i in range(n + d + m)]
+        eng = autogp.HipEngine.__new__(autogp.HipEngine)
+        eng.ctx = ctx
+        model = autogp.GPModel(dates[:n], w.y, n_particles=P_total, engine=eng, seed=5)
+        sl = distributed.shard(P_total)
+        mine = order[sl]
+        model.particles = [autogp.Particle(gp.from_program(w.programs[i][0], w.programs[i][1]),
+                                           float(w.programs[i][2])) for i in mine]
+        model.n_obs = n
+        tm_, ym_ = model._obs()
+        lm0, info0 = eng.logml(model.programs(), tm_, ym_)
+        assert not info0.any()
+        model._logml, model.log_weights = lm0, np.zeros(len(mine))
+        scen = nc.create_nowcast_data([row for row in w.y_add], dates[n:n + d])
+        fdates = dates[n + d:]
+        hmc = {"n_leapfrog": args.hmc_leapfrog, "eps": 0.01}
         P = len(mine)
-        Y = np.empty((P * D, n + d))
-        Y[:, :n] = w.y
-        Y[:, n:] = np.tile(w.y_add, (P, 1))
-        tt = np.concatenate([w.t, w.t_add])
+        evals_per_item = hmc["n_leapfrog"] + 2     # leapfrog + 1 gradient evaluations + 1 predict
+
+        def step():
+            fc = nc.forecast_with_nowcasts(model, scen, fdates, 20, n_hmc=1, ess_threshold=1.0,
+                                           hmc_config=hmc)
+            return {"info": np.zeros(1, dtype=np.int32), "fc": fc}, None
     else:
         w, progs, Y, tt = bench_items(args.config, rank, args.n, args.particles, args.scenarios)
         P, D, n, d, m = len(w.programs), w.y_add.shape[0], w.n, w.t_add.size, w.t_new.size
         P_total = P
+        if grad_mode:
+            from nowcastautogp_amd._abi import KernelArray
+            ka = KernelArray(progs)
+
+            def step():
+                lm, g, info = ctx.logml_grad_flat(ka, tt, Y)
+                return {"info": info, "logml_full": lm, "grad": g}, None
+        else:
+            if precision == "mixed":
+                ctx.set_spec(default_spec(NGP_PREC_MIXED))
+            job = ctx.stage_predict(progs, tt, Y, w.t_new)        # inputs now resident in HBM
+            ctx.set_spec(default_spec())
+            logw_prev = np.zeros((P, D))
+
+            def step():
+                job.run()
+                out = job.fetch()
+                # add_data! weight update + maybe_resample! normalisation: per scenario over ALL particles
+                logw = logw_prev + out["logml_full"].reshape(P, D)
+                return out, distributed.normalize_log_weights(logw, device=dev, P_total=P * world)
     B = P * D
-
-    ctx = _lib.Context(local_rank)
-    if precision == "mixed":
-        ctx.set_spec(default_spec(NGP_PREC_MIXED))
-    job = ctx.stage_predict(progs, tt, Y, w.t_new)        # inputs now resident in HBM
-    ctx.set_spec(default_spec())
-    logw_prev = np.zeros((P, D))
-    descr = [(progs[p * D][0], progs[p * D][1], progs[p * D][2]) for p in range(P)]
-
-    def step():
-        job.run()
-        out = job.fetch()
-        # add_data! weight update + maybe_resample! normalisation: per scenario over ALL particles
-        logw = logw_prev + out["logml_full"].reshape(P, D)
-        if sharded:
-            wn, ess = distributed.normalize_log_weights(logw, device=dev, P_total=P_total)
-            # resample exchange: per scenario the ancestors are drawn on every rank from the same
-            # seed; ONE all-gather of the particle descriptors serves all scenarios
-            w_all = distributed.all_gather_rows(wn, dev, distributed.block_sizes(P_total))
-            anc = [distributed.resample_ancestors(w_all[:, s], 1000 + s) for s in range(min(D, 8))]
-            new = distributed.exchange_particles(descr, anc[0])
-            return out, (wn, ess, len(new))
-        return out, distributed.normalize_log_weights(logw, device=dev, P_total=P * world)
 
     for _ in range(args.warmup):
         step()
@@ -334,7 +506,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile_get()
-    mixed_stats = job.mixed_stats() if precision == "mixed" else None
+    mixed_stats = job.mixed_stats() if (precision == "mixed" and job is not None) else None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -342,12 +514,16 @@ def main():
     bad = int((out["info"] != 0).sum())
 
     if args.headline_only:
-        args.no_fit = args.no_cpu_baseline = True
+        args.no_fit = args.no_cpu_baseline = args.no_other_configs = True
+    if sharded or grad_mode:
+        args.no_fit = args.no_other_configs = True
+    if sharded:
+        args.no_cpu_baseline = True      # the step's outputs are draws, not per-item logml's
     shared_ms = cached_ms = f64_ms = None
-    if not args.headline_only and args.config in ("C3", "C4"):
+    if not args.headline_only and not grad_mode and args.config in ("C3", "C4"):
         # shared-K mode of the same workload (default n_mcmc = n_hmc = 0 path), rank-local,
         # untimed against `value`: reported separately
-        sub = [w.programs[i] for i in (mine if sharded else range(P))]
+        sub = [w.programs[int(i)] for i in (mine if sharded else range(P))]
         job2 = ctx.stage_nowcast(sub, w.t, w.y, w.t_add, w.y_add, w.t_new)
         job2.run()
         ts = time.perf_counter()
@@ -364,7 +540,7 @@ def main():
             fac.nowcast(w.t_add, w.y_add, w.t_new)
         cached_ms = (time.perf_counter() - ts) / 3 * 1e3
         fac.close()
-    if not args.headline_only and precision == "mixed":
+    if not args.headline_only and precision == "mixed" and job is not None:
         # the fp64 path on the same items, beside the mixed-precision figure
         jobf = ctx.stage_predict(progs, tt, Y, w.t_new)
         jobf.run()
@@ -381,20 +557,31 @@ def main():
 
     if rank == 0:
         zero = dict(ms=0.0, flops=0.0, launches=0, bytes=0.0)
-        mixed = precision == "mixed"
-        col = prof.get("chol_col_mixed" if mixed else "chol_col", zero)   # the fat steps
-        thin = prof.get("chol_col_thin", zero)      # chol_col_kernel: thin / full steps
+        mixed = precision == "mixed" and not grad_mode and not sharded
         # diag_ahead runs on a side stream beside chol_diag / the thin step: not part of the sum
         total_ms = sum(v["ms"] for k, v in prof.items() if k != "diag_ahead")
+        # the dominant kernel: the fat steps of the column sweep in the predict mode (as in every
+        # earlier round); in the gradient / C4 modes whichever class took the most device time
+        if grad_mode or sharded:
+            dom_key = max((k for k in prof if k != "diag_ahead"), key=lambda k: prof[k]["ms"])
+        else:
+            dom_key = "chol_col_mixed" if mixed else "chol_col"
+        col = prof.get(dom_key, zero)
+        thin = prof.get("chol_col_thin", zero)      # chol_col_kernel: thin / full steps
         ach = col["flops"] / (col["ms"] * 1e-3) * 1e-12 if col["ms"] else 0.0
-        both_ms = col["ms"] + thin["ms"]
-        ach_both = (col["flops"] + thin["flops"]) / (both_ms * 1e-3) * 1e-12 if both_ms else 0.0
+        fat = prof.get("chol_col_mixed" if mixed else "chol_col", zero)
+        both_ms = fat["ms"] + thin["ms"]
+        ach_both = (fat["flops"] + thin["flops"]) / (both_ms * 1e-3) * 1e-12 if both_ms else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if mixed else FP64_MFMA_PEAK_TFLOPS
-        kern_key = "chol_col_glds_kernel<true>" if mixed else "chol_col_glds_kernel<false>"
-        fat_steps = ((n // 64) // 2)                       # fat launches one item goes through
+        kern_key = KERNEL_OF_CLASS.get(dom_key, dom_key)
+        npts = n + d if not grad_mode else n + d
+        nb = (npts + 63) // 64 if grad_mode else npts // 64      # gradient jobs pad to a block
+        fat_steps = nb // 2                                 # fat launches one item goes through
         per_launch = B * fat_steps * args.steps / max(col["launches"], 1)
-        traffic, traffic_src = measured_traffic(args.config, kern_key, per_launch)
+        pmc_name = args.config + ("_grad" if grad_mode else "")
+        traffic, traffic_src = measured_traffic(pmc_name, kern_key, per_launch)
         names = {"C1": "C1", "C2": "C2", "C3": "C3", "C4": "C4", "C5": "C5"}[args.config]
+        F_item = F_logml_grad(npts) if grad_mode else F_logml(npts)
         roof = {
             "bound": "mfma",
             "kernel": ("chol_col_glds_kernel<MIXED> (the fat steps of the column sweep: per 64-wide "
@@ -403,7 +590,11 @@ def main():
                        "the fp64 path; fp64 accumulators, solve and stored factor)") if mixed else
                       ("chol_col_glds_kernel (the fat steps of the column sweep: "
                        "v_mfma_f64_4x4x4_4b_f64 trailing update of two block columns from "
-                       "LDS-DMA staged operands, in-register 64-wide triangular solve)"),
+                       "LDS-DMA staged operands, in-register 64-wide triangular solve"
+                       + ("; in a gradient job the aux block is [I ; y'], so the sweep also "
+                          "produces W = L^-T, block upper triangular)" if grad_mode or sharded
+                          else ")")) if dom_key == "chol_col" else kern_key,
+            "timing_class": dom_key,
             "achieved": ach,
             "peak": peak,
             "unit": "TFLOP/s",
@@ -418,10 +609,19 @@ def main():
             "share_of_kernel_time": col["ms"] / total_ms if total_ms else 0.0,
             "with_thin_steps": {"what": "fat + thin / full steps (the whole column sweep)",
                                 "achieved": ach_both, "frac": ach_both / peak},
-            "algorithmic_flops_per_item": F_logml(n + d),
-            "whole_path_tflops": B * args.steps * F_logml(n + d) / (total_ms * 1e-3) * 1e-12
-            if total_ms else 0.0,
+            "algorithmic_flops_per_item": F_item,
         }
+        if not sharded:
+            roof["whole_path_tflops"] = (B * args.steps * F_item / (total_ms * 1e-3) * 1e-12
+                                         if total_ms else 0.0)
+            roof["whole_path_frac"] = roof["whole_path_tflops"] / peak
+        if grad_mode:
+            kv = prof.get("grad_kinv", zero)
+            roof["grad_kinv"] = {
+                "kernel": KERNEL_OF_CLASS["grad_kinv"],
+                "achieved": kv["flops"] / (kv["ms"] * 1e-3) * 1e-12 if kv["ms"] else 0.0,
+                "frac": (kv["flops"] / (kv["ms"] * 1e-3) * 1e-12 / peak) if kv["ms"] else 0.0,
+                "avg_launch_ms": kv["ms"] / max(kv["launches"], 1), "launches": kv["launches"]}
         if mixed:
             f32 = float(np.mean(mixed_stats["frac_f32"]))
             roof["peak_basis"] = ("dense fp32 MFMA (v_mfma_f32_32x32x2_f32), the guide's 'Peak FP32 "
@@ -435,12 +635,26 @@ def main():
             roof["measured_issue_ceiling"] = {"v_mfma_f64_4x4x4_4b_f64": 75.0,
                                               "v_mfma_f64_16x16x4_f64": 49.5, "unit": "TFLOP/s",
                                               "source": "profiles/r01/ubench_mfma*.log"}
-        res = {
-            "metric": "particle-logml/s (fit+forecast hot path: covariance assembly + Cholesky + "
+        if grad_mode:
+            metric = ("particle-logml+gradient/s (the HMC leapfrog of fit_smc! / mcmc_parameters!: "
+                      "covariance assembly + Cholesky + K^-1 + reverse-mode contraction per item), "
+                      f"n={n} {P_total}-particle SMC")
+            unit = "particle-logml+gradient/s"
+        elif sharded:
+            metric = ("particle-logml/s through the product's forecast_with_nowcasts in the HMC "
+                      f"refinement mode ({evals_per_item - 1} of every {evals_per_item} evaluations "
+                      f"per (particle, scenario) carry a gradient), n={n} {P_total}-particle SMC")
+            unit = "particle-logml/s"
+        else:
+            metric = ("particle-logml/s (fit+forecast hot path: covariance assembly + Cholesky + "
                       "logml + predictive per (particle, scenario) item), "
-                      f"n={n} {P_total}-particle SMC",
-            "value": B * world * args.steps / elapsed,
-            "unit": "particle-logml/s",
+                      f"n={n} {P_total}-particle SMC")
+            unit = "particle-logml/s"
+        total_items = (P_total * D if sharded else B * world) * evals_per_item
+        res = {
+            "metric": metric,
+            "value": total_items * args.steps / elapsed,
+            "unit": unit,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -455,7 +669,13 @@ def main():
                                     + (f"{P_total} particles sharded {P} per GPU (dealt by tree size)"
                                        if sharded else f"{P} particles")
                                     + f" x {D} nowcast scenario(s) per GPU, m={m} forecast points, "
-                                    "every item its own kernel parameters (no dedupe)"),
+                                    + ("one model, forecast_with_nowcasts(n_hmc=1, ess_threshold=1, "
+                                       f"{evals_per_item - 2} leapfrog(s)) per step: lockstep calls of "
+                                       f"{B} items per GPU" if sharded else
+                                       "every item its own kernel parameters (no dedupe)")
+                                    + ("; step = ONE logml + gradient call (inputs cross PCIe "
+                                       "inside the call: there is no staged gradient job)"
+                                       if grad_mode else "")),
                        "items_per_gpu": B,
                        "parallelism": f"particles sharded x{world}" if sharded
                        else f"replicated config x{world}"},
@@ -497,9 +717,20 @@ def main():
                                                out["logml_full"].reshape(-1))
             if "value" in res["cpu_baseline"]:
                 res["speedup_vs_cpu_port"] = res["value"] / res["cpu_baseline"]["value"]
+        if not args.no_other_configs and args.config == "C3" and world == 1:
+            # release the headline's device memory first: the children size their chunks by
+            # what is free
+            if job is not None:
+                job.close()
+                job = None
+            ctx.close()
+            ctx = None
+            res["other_configs"] = other_configs(args)
         print(json.dumps(res))
-    job.close()
-    ctx.close()
+    if job is not None:
+        job.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -294,11 +294,12 @@ void       ngp_factor_destroy(ngp_factor *f);
  * HIP-event timing of the kernels a job launches, on the stream they are
  * launched on.  Classes: 0 = chol_col_glds_kernel (fat steps: trailing-update
  * GEMM + fused solve, the dominant kernel), 1 = chol_diag, 2 = gram,
- * 3 = epilogue, 4 = cov fill, 5 = gradient kernels, 6 = chol_col_kernel (thin /
+ * 3 = epilogue, 4 = cov fill, 5 = K^-1 = W W' of a gradient job (grad_kinv*), 6 = chol_col_kernel (thin /
  * full steps, aux solves of a resident factor), 7 = aux_update_kernel,
  * 8 = diag_ahead_kernel (side stream, overlaps classes 1 and 6), 9 = the
  * mixed-precision fat steps (chol_col_glds_kernel<MIXED>), 10 = Gram refinement
- * of NGP_PREC_MIXED (backward sweep, covariance apply, small products).        */
+ * of NGP_PREC_MIXED (backward sweep, covariance apply, small products), 11 = the
+ * reverse-mode contraction of a gradient job (grad_alpha / grad_contract* / grad_reduce). */
 #define NGP_NUM_KERNEL_CLASSES 12
 typedef struct ngp_profile {
     double   ms[NGP_NUM_KERNEL_CLASSES];       /* summed device time per class */

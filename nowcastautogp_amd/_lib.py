@@ -19,8 +19,8 @@ from ._abi import (KernelArray, NgpKernel, NgpProfile, NgpSpec, as_f64, c_double
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NGP_LIB") or os.path.join(_HERE, "libngp.so")  # NGP_LIB: A/B builds
 
-KERNEL_CLASSES = ("chol_col", "chol_diag", "gram", "epilogue", "fill", "grad", "chol_col_thin",
-                  "aux_update", "diag_ahead", "chol_col_mixed", "refine", "reserved")
+KERNEL_CLASSES = ("chol_col", "chol_diag", "gram", "epilogue", "fill", "grad_kinv", "chol_col_thin",
+                  "aux_update", "diag_ahead", "chol_col_mixed", "refine", "grad_contract")
 
 # every symbol include/ngp.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = (

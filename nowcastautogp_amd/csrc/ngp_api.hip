@@ -256,10 +256,19 @@ struct ngp_ctx {
     bool profiling = false;
     ngp_profile prof{};
     size_t mem_cap = 0;  // bytes the factor storage of one job may take
-    // caching allocator: repeated jobs of the same shape (the SMC/MCMC loop) reuse blocks
+    // caching allocator: repeated jobs of the same shape (the SMC/MCMC loop, the steps of a
+    // staged batch) reuse blocks.  A context that cannot allocate first gives its own cache back
+    // to the device, then the caches of the process's other contexts (registry below).
     std::multimap<size_t, void *> free_blocks;
     std::map<void *, size_t> live;
+    size_t cached_bytes = 0;
 
+    void drop_cache() {
+        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+        cached_bytes = 0;
+    }
+    static void drop_other_caches(ngp_ctx *self);
     ngp_status alloc(void **p, size_t bytes) {
         bytes = (bytes + 255) / 256 * 256;
         if (bytes == 0) bytes = 256;
@@ -267,15 +276,21 @@ struct ngp_ctx {
         if (it != free_blocks.end() && it->first <= bytes * 2) {
             *p = it->second;
             live[*p] = it->first;
+            cached_bytes -= it->first;
             free_blocks.erase(it);
             return NGP_OK;
         }
         hipError_t e = hipMalloc(p, bytes);
-        if (e != hipSuccess) {  // drop the cache and retry once
-            for (auto &kv : free_blocks) (void)hipFree(kv.second);
-            free_blocks.clear();
+        for (int attempt = 0; e != hipSuccess && attempt < 2; ++attempt) {
+            (void)hipGetLastError();   // handled here: must not surface as the job's last error
+            if (attempt == 0) drop_cache();
+            else drop_other_caches(this);
             e = hipMalloc(p, bytes);
-            if (e != hipSuccess) return NGP_ERR_TOO_LARGE;
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            *p = nullptr;
+            return NGP_ERR_TOO_LARGE;
         }
         live[*p] = bytes;
         return NGP_OK;
@@ -285,9 +300,32 @@ struct ngp_ctx {
         auto it = live.find(p);
         if (it == live.end()) return;
         free_blocks.emplace(it->second, p);
+        cached_bytes += it->second;
         live.erase(it);
     }
+    // bytes a job's factor storage may take: 3/4 of what the device has free now plus what this
+    // context's cache would give back (the figure of ngp_ctx_create goes stale as soon as another
+    // context or a resident factor allocates)
+    void refresh_mem_cap() {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess)
+            mem_cap = (size_t)(0.75 * (double)(fr + cached_bytes));
+    }
 };
+
+// every live context of the process (alloc falls back on the others' caches)
+static std::mutex g_ctx_registry_mu;
+static std::vector<ngp_ctx *> g_ctx_registry;
+void ngp_ctx::drop_other_caches(ngp_ctx *self) {
+    std::lock_guard<std::mutex> lk(g_ctx_registry_mu);
+    for (ngp_ctx *o : g_ctx_registry) {
+        if (o == self || o->device != self->device) continue;
+        if (o->mu.try_lock()) {   // a context in the middle of a call keeps its cache
+            o->drop_cache();
+            o->mu.unlock();
+        }
+    }
+}
 
 static DevSpec dev_spec(const ngp_spec &s) {
     return DevSpec{s.se_form, s.periodic_form, s.cp_form, s.precision, s.jitter, s.mixed_tau};
@@ -352,12 +390,21 @@ extern "C" ngp_status ngp_ctx_create(int32_t device, ngp_ctx **out) {
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) == hipSuccess) c->mem_cap = (size_t)(0.75 * (double)fr);
     else c->mem_cap = (size_t)8 << 30;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_registry_mu);
+        g_ctx_registry.push_back(c);
+    }
     *out = c;
     return NGP_OK;
 }
 
 extern "C" void ngp_ctx_destroy(ngp_ctx *c) {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_registry_mu);
+        g_ctx_registry.erase(std::remove(g_ctx_registry.begin(), g_ctx_registry.end(), c),
+                             g_ctx_registry.end());
+    }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->free_blocks) (void)hipFree(kv.second);
@@ -853,6 +900,7 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
         // as few chunks as the memory allows, of equal size (a short last chunk runs every launch
         // of the sweep again for a fraction of the items)
         // (several kernels index the items of a chunk with blockIdx.y: at most 65,535 of them)
+        if ((size_t)g.B * item_bytes > c->mem_cap) c->refresh_mem_cap();   // large job: today's figure
         const size_t bc_max = std::min<size_t>(
             std::min<size_t>((size_t)g.B, MAX_CHUNK_ITEMS), std::max<size_t>(1, c->mem_cap / item_bytes));
         size_t nchunks = ((size_t)g.B + bc_max - 1) / bc_max;
@@ -1463,28 +1511,35 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
     const size_t item_bytes = l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 +
                               8 * (size_t)g.n0 + 8 * (size_t)ntri * GP;
+    if ((size_t)B * item_bytes > c->mem_cap) c->refresh_mem_cap();   // large job: today's figure
     int Bc = (int)std::min<size_t>(std::min<size_t>((size_t)B, MAX_CHUNK_ITEMS),
                                    std::max<size_t>(1, c->mem_cap / item_bytes));
     void *d_prog, *d_t, *d_y, *d_q = nullptr, *d_logdet, *d_info, *d_L, *d_dinv, *d_tab = nullptr,
          *d_sig = nullptr, *d_dtab = nullptr, *d_kinv, *d_alpha, *d_quad, *d_part, *d_grad, *d_logml;
     ngp_status st;
-    if ((st = dalloc(&d_prog, sizeof(DevProgram) * (size_t)B)) ||
-        (st = dalloc(&d_t, 8 * (size_t)g.n0)) || (st = dalloc(&d_y, 8 * h_y.size())) ||
-        (g.lattice && (st = dalloc(&d_q, 4 * (size_t)g.n0))) ||
-        (st = dalloc(&d_logdet, 8 * (size_t)B)) || (st = dalloc(&d_info, 4 * (size_t)B)) ||
-        (st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
-        (st = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
-        (g.lattice && ((st = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
-                       (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)) ||
-                       (st = dalloc(&d_dtab, 3 * tab_bytes * (size_t)Bc)))) ||
-        (st = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||
-        (st = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) || (st = dalloc(&d_quad, 8 * (size_t)Bc)) ||
-        // a chunk that is cut finer (split 2 or 4) writes at most 4096 partial rows; a coarse one Bc ntri
-        (st = dalloc(&d_part, 8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc),
-                                                   4096) * GP)) ||
-        (st = dalloc(&d_grad, 8 * (size_t)B * GP)) || (st = dalloc(&d_logml, 8 * (size_t)B))) {
+    // the chunk is halved when the device cannot hold it after all (other handles, rounding)
+    for (;; Bc = (Bc + 1) / 2) {
+        if (!((st = dalloc(&d_prog, sizeof(DevProgram) * (size_t)B)) ||
+              (st = dalloc(&d_t, 8 * (size_t)g.n0)) || (st = dalloc(&d_y, 8 * h_y.size())) ||
+              (g.lattice && (st = dalloc(&d_q, 4 * (size_t)g.n0))) ||
+              (st = dalloc(&d_logdet, 8 * (size_t)B)) || (st = dalloc(&d_info, 4 * (size_t)B)) ||
+              (st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
+              (st = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
+              (g.lattice && ((st = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
+                             (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)) ||
+                             (st = dalloc(&d_dtab, 3 * tab_bytes * (size_t)Bc)))) ||
+              (st = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||
+              (st = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) ||
+              (st = dalloc(&d_quad, 8 * (size_t)Bc)) ||
+              // a chunk that is cut finer (split 2 or 4) writes at most 4096 partial rows; a coarse one Bc ntri
+              (st = dalloc(&d_part,
+                           8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc), 4096) *
+                               GP)) ||
+              (st = dalloc(&d_grad, 8 * (size_t)B * GP)) || (st = dalloc(&d_logml, 8 * (size_t)B))))
+            break;
         freeall();
-        return st;
+        owned.clear();
+        if (st != NGP_ERR_TOO_LARGE || Bc <= 1) return st;
     }
     hipError_t e = hipMemcpyAsync(d_prog, hp.data(), sizeof(DevProgram) * (size_t)B,
                                   hipMemcpyHostToDevice, s);
@@ -1520,7 +1575,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
             launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
                              (double *)d_quad, bc, s);
         });
-        tm.run(5, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
+        tm.run(11, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
             launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
                                  (const double *)d_quad, (double *)d_part,
                                  (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc,

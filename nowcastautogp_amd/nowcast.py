@@ -123,22 +123,25 @@ def _apply(inv_transformation: Callable, a: np.ndarray) -> np.ndarray:
 
 def forecast(model: GPModel, forecast_dates, forecast_draws: int, *,
              inv_transformation: Callable = lambda y: y,
-             forecast_n_hmc: Optional[int] = None) -> np.ndarray:
-    """Matrix (len(forecast_dates), forecast_draws) of samples (reference src/forecasting.jl:29-75)."""
+             forecast_n_hmc: Optional[int] = None, hmc_config: Optional[dict] = None) -> np.ndarray:
+    """Matrix (len(forecast_dates), forecast_draws) of samples (reference src/forecasting.jl:29-75).
+    ``hmc_config`` (not in the reference's signature; AutoGP's default applies there): leapfrog
+    count and step size of the HMC moves, ``{"n_leapfrog": ..., "eps": ...}``."""
     dates = list(forecast_dates)
     if forecast_n_hmc is None:
         draws = autogp.predict_mvn(model, dates).rand(int(forecast_draws))
     else:
         draws = np.empty((len(dates), int(forecast_draws)))
         for i in range(int(forecast_draws)):
-            autogp.mcmc_parameters(model, forecast_n_hmc)
+            autogp.mcmc_parameters(model, forecast_n_hmc, hmc_config)
             draws[:, i] = autogp.predict_mvn(model, dates).rand()
     return _apply(inv_transformation, draws)
 
 
 def forecast_lockstep(models: Sequence[GPModel], forecast_dates, forecast_draws: int, *,
                       inv_transformation: Callable = lambda y: y,
-                      forecast_n_hmc: Optional[int] = None) -> List[np.ndarray]:
+                      forecast_n_hmc: Optional[int] = None,
+                      hmc_config: Optional[dict] = None) -> List[np.ndarray]:
     """``forecast`` (reference src/forecasting.jl:29-75) of D models on the same dates at once."""
     dates = list(forecast_dates)
     k = int(forecast_draws)
@@ -148,7 +151,7 @@ def forecast_lockstep(models: Sequence[GPModel], forecast_dates, forecast_draws:
     else:
         out = [np.empty((len(dates), k)) for _ in models]
         for i in range(k):       # src/forecasting.jl:63-68: HMC on the parameters before every draw
-            autogp.mcmc_parameters_lockstep(models, forecast_n_hmc)
+            autogp.mcmc_parameters_lockstep(models, forecast_n_hmc, hmc_config)
             for o, mix in zip(out, autogp.predict_mvn_lockstep(models, dates)):
                 o[:, i] = mix.rand()
     return [_apply(inv_transformation, o) for o in out]
@@ -159,7 +162,10 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
                            inv_transformation: Callable = lambda y: y, n_mcmc: int = 0,
                            n_hmc: int = 0, ess_threshold: float = 0.0,
                            forecast_n_hmc: Optional[int] = None, verbose: bool = False,
-                           lockstep: bool = True) -> np.ndarray:
+                           lockstep: bool = True, hmc_config: Optional[dict] = None) -> np.ndarray:
+    """reference src/forecasting.jl:117-167.  Two keywords are this module's own: ``lockstep``
+    (False: the reference's per-scenario loop, one clone after another) and ``hmc_config``
+    (leapfrog count / step size of the refinement moves; AutoGP's defaults apply in the reference)."""
     assert len(nowcasts) > 0, "nowcasts vector must not be empty"
     assert not (n_mcmc > 0 and n_hmc == 0), \
         "If n_mcmc > 0, n_hmc must also be > 0 for MCMC refinement"
@@ -189,11 +195,11 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
                                  base=base_model)
         autogp.maybe_resample_lockstep(models, ess_threshold * autogp.num_particles(base_model))
         if n_mcmc > 0 and n_hmc > 0:
-            autogp.mcmc_structure_lockstep(models, n_mcmc, n_hmc)
+            autogp.mcmc_structure_lockstep(models, n_mcmc, n_hmc, hmc_config)
         elif n_mcmc == 0 and n_hmc > 0:
-            autogp.mcmc_parameters_lockstep(models, n_hmc)
+            autogp.mcmc_parameters_lockstep(models, n_hmc, hmc_config)
         results = forecast_lockstep(models, dates, draws, inv_transformation=inv_transformation,
-                                    forecast_n_hmc=forecast_n_hmc)
+                                    forecast_n_hmc=forecast_n_hmc, hmc_config=hmc_config)
         if verbose:
             print(f"Nowcast scenarios: {len(results)}/{len(nowcasts)} (lockstep)")
         return np.hstack(results)
@@ -203,11 +209,11 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
         autogp.add_data(m, nc.ds, nc.y)
         autogp.maybe_resample(m, ess_threshold * autogp.num_particles(m))
         if n_mcmc > 0 and n_hmc > 0:
-            autogp.mcmc_structure(m, n_mcmc, n_hmc)
+            autogp.mcmc_structure(m, n_mcmc, n_hmc, hmc_config)
         elif n_mcmc == 0 and n_hmc > 0:
-            autogp.mcmc_parameters(m, n_hmc)
+            autogp.mcmc_parameters(m, n_hmc, hmc_config)
         results.append(forecast(m, dates, draws, inv_transformation=inv_transformation,
-                                forecast_n_hmc=forecast_n_hmc))
+                                forecast_n_hmc=forecast_n_hmc, hmc_config=hmc_config))
         if verbose:
             print(f"Nowcast scenarios: {len(results)}/{len(nowcasts)}")
     return np.hstack(results)

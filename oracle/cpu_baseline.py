@@ -12,6 +12,7 @@ i.e. what AutoGP does per (particle, scenario) under add_data! / predict_mvn.
 
     python oracle/cpu_baseline.py --config C3 --rank 0 --items 0,50,100 --workers 8
     python oracle/cpu_baseline.py --sizes 205,410,2048 --per-size 2            (logml only)
+    python oracle/cpu_baseline.py --sizes 205,2048 --with-grad        (+ logml and gradient)
 
 prints ONE JSON line.
 """
@@ -47,6 +48,15 @@ def _predict(i):
     return i, float(lm), int(info), time.perf_counter() - t0
 
 
+def _grad_item(i):
+    """logml + gradient of item i (the gradient mode of bench.py: an HMC leapfrog evaluation)"""
+    from oracle import oracle_np
+    w, progs, Y, tt = _G["items"]
+    t0 = time.perf_counter()
+    lm, g, info = oracle_np.logml_grad(progs[i], tt, Y[i])
+    return i, float(lm), int(info), time.perf_counter() - t0
+
+
 def _logml_size(arg):
     from oracle import oracle_np
     ns, k = arg
@@ -54,6 +64,18 @@ def _logml_size(arg):
     prog = progs[(k * 7919) % len(progs)]
     t0 = time.perf_counter()
     oracle_np.logml(prog, tt[:ns], Y[0, :ns])
+    return ns, time.perf_counter() - t0
+
+
+def _grad_size(arg):
+    """one logml + gradient evaluation the way a CPU does it efficiently (oracle_np.logml_grad:
+    dpotrf + dpotri + one reverse sweep of the kernel tree), same item choice as _logml_size"""
+    from oracle import oracle_np
+    ns, k = arg
+    w, progs, Y, tt = _G["items"]
+    prog = progs[(k * 7919) % len(progs)]
+    t0 = time.perf_counter()
+    oracle_np.logml_grad(prog, tt[:ns], Y[0, :ns])
     return ns, time.perf_counter() - t0
 
 
@@ -96,6 +118,9 @@ def main():
     ap.add_argument("--items", default="")
     ap.add_argument("--sizes", default="")
     ap.add_argument("--per-size", type=int, default=2)
+    ap.add_argument("--with-grad", action="store_true",
+                    help="with --sizes: also time logml + gradient evaluations at those sizes; "
+                         "with --items: the items are logml + gradient evaluations")
     ap.add_argument("--workers", type=int, default=0,
                     help="worker processes; 0 = every usable core (affinity mask and cgroup quota)")
     ap.add_argument("--max-workers", type=int, default=0, help="cap on the automatic choice")
@@ -111,10 +136,11 @@ def main():
            "cgroup_cpu_quota": quota, "host_cores": os.cpu_count()}
     if a.items:
         idx = [int(x) for x in a.items.split(",")]
+        _item = _grad_item if a.with_grad else _predict
         with ctx.Pool(a.workers, initializer=_init, initargs=init) as pool:
-            pool.map(_predict, idx[:a.workers])          # warm: imports, page-in, first BLAS call
+            pool.map(_item, idx[:a.workers])             # warm: imports, page-in, first BLAS call
             t0 = time.perf_counter()
-            res = pool.map(_predict, idx, chunksize=1)
+            res = pool.map(_item, idx, chunksize=1)
             wall = time.perf_counter() - t0
         out.update(items=[r[0] for r in res], logml=[r[1] for r in res], info=[r[2] for r in res],
                    wall_s=wall, items_per_s=len(idx) / wall,
@@ -122,9 +148,9 @@ def main():
         if a.one_core_items > 0:
             k = idx[:a.one_core_items]
             with ctx.Pool(1, initializer=_init, initargs=init) as pool:
-                pool.map(_predict, k[:1])
+                pool.map(_item, k[:1])
                 t0 = time.perf_counter()
-                pool.map(_predict, k, chunksize=1)
+                pool.map(_item, k, chunksize=1)
                 w1 = time.perf_counter() - t0
             out.update(one_core_items_per_s=len(k) / w1)
     if a.sizes:
@@ -137,6 +163,14 @@ def main():
         for ns, dt in res:
             per.setdefault(ns, []).append(dt)
         out["logml_s_per_item_by_n"] = {str(k): float(np.mean(v)) for k, v in per.items()}
+        if a.with_grad:
+            with ctx.Pool(min(a.workers, len(jobs)), initializer=_init, initargs=init) as pool:
+                pool.map(_grad_size, jobs[:1])
+                res = pool.map(_grad_size, jobs, chunksize=1)
+            perg = {}
+            for ns, dt in res:
+                perg.setdefault(ns, []).append(dt)
+            out["logml_grad_s_per_item_by_n"] = {str(k): float(np.mean(v)) for k, v in perg.items()}
     print(json.dumps(out))
 
 

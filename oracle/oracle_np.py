@@ -186,6 +186,105 @@ def logml_grad_fd(program, t, y, spec=None, rel=1e-6):
     return g
 
 
+def _eval_adjoint(node, T1, T2, sp, A, out):
+    """Reverse-mode sweep of the kernel tree: returns the node's value matrix and appends to
+    ``out``, in postfix (RPN) parameter order, sum(A * d value / d param) for the node's own
+    parameters after those of its subtrees.  ``A`` is the adjoint of the node's value."""
+    op, pr, l, r = node
+    if op == 1:
+        out.append(float(A.sum()))
+        return np.full(A.shape, pr[0])
+    if op == 2:
+        c, bias, amp = pr
+        u, v = T1 - c, T2 - c
+        out.extend([float((A * (-amp * (u + v))).sum()), float(A.sum()), float((A * (u * v)).sum())])
+        return bias + amp * u * v
+    if op == 3:
+        ls, amp = pr
+        d2 = (T1 - T2) ** 2
+        den = ls if sp["se_form"] else ls * ls
+        e = np.exp(-0.5 * d2 / den)
+        dden = 1.0 if sp["se_form"] else 2.0 * ls
+        out.extend([float((A * (amp * e * 0.5 * d2 / (den * den) * dden)).sum()),
+                    float((A * e).sum())])
+        return amp * e
+    if op == 4:
+        ls, gam, amp = pr
+        d = np.abs(T1 - T2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = d / ls
+            pw = np.power(q, gam)
+            lq = np.where(q > 0, np.log(np.where(q > 0, q, 1.0)), 0.0)
+        e = np.exp(-pw)
+        out.extend([float((A * (amp * e * pw * gam / ls)).sum()),
+                    float((A * (-amp * e * pw * lq)).sum()), float((A * e).sum())])
+        return amp * e
+    if op == 5:
+        ls, per, amp = pr
+        d = np.abs(T1 - T2)
+        c = 2.0 / ls if sp["periodic_form"] else 2.0 / (ls * ls)
+        dc = -2.0 / (ls * ls) if sp["periodic_form"] else -4.0 / (ls * ls * ls)
+        arg = np.pi * d / per
+        sn = np.sin(arg)
+        e = np.exp(-c * sn * sn)
+        out.extend([float((A * (-amp * e * sn * sn * dc)).sum()),
+                    float((A * (amp * e * c * 2.0 * sn * np.cos(arg) * arg / per)).sum()),
+                    float((A * e).sum())])
+        return amp * e
+    if op == 6:
+        return _eval_adjoint(l, T1, T2, sp, A, out) + _eval_adjoint(r, T1, T2, sp, A, out)
+    if op == 7:
+        # the adjoint of each factor needs the other factor's value: evaluate both first
+        vl, vr = _eval(l, T1, T2, sp), _eval(r, T1, T2, sp)
+        _eval_adjoint(l, T1, T2, sp, A * vr, out)
+        _eval_adjoint(r, T1, T2, sp, A * vl, out)
+        return vl * vr
+    if op == 8:
+        loc, sc = pr
+        sgn = -1.0 if sp["cp_form"] else 1.0
+        u1, u2 = sgn * (loc - T1) / sc, sgn * (loc - T2) / sc
+        s1, s2 = 0.5 * (1 + np.tanh(u1)), 0.5 * (1 + np.tanh(u2))
+        vl = _eval_adjoint(l, T1, T2, sp, A * (s1 * s2), out)
+        vr = _eval_adjoint(r, T1, T2, sp, A * ((1 - s1) * (1 - s2)), out)
+        ds1, ds2 = 2.0 * s1 * (1 - s1), 2.0 * s2 * (1 - s2)        # d sigma / d u
+        # d value / d s1 = vl s2 - vr (1 - s2), likewise for s2; du/dloc = sgn / sc, du/dsc = -u / sc
+        g1 = vl * s2 - vr * (1 - s2)
+        g2 = vl * s1 - vr * (1 - s1)
+        out.extend([float((A * (g1 * ds1 + g2 * ds2) * (sgn / sc)).sum()),
+                    float((A * (g1 * ds1 * (-u1 / sc) + g2 * ds2 * (-u2 / sc))).sum())])
+        return s1 * vl * s2 + (1 - s1) * vr * (1 - s2)
+    raise ValueError(op)
+
+
+def logml_grad(program, t, y, spec=None):
+    """logml and its gradient with respect to (params in RPN order, noise) the way a CPU
+    implementation would do it efficiently: one Cholesky, K^-1 from the factor (dpotri), and ONE
+    reverse-mode sweep of the kernel tree contracted with (alpha alpha' - K^-1) / 2.  Used as the
+    CPU price of a logml + gradient evaluation in bench.py (the C oracle's gradient is forward
+    mode: a different, slower algorithm) and cross-checked against it in tests/test_oracle.py."""
+    from scipy.linalg import lapack
+    ops, params, noise = program
+    sp = _spec(spec)
+    t = np.asarray(t, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    n = t.size
+    L, info = _factor(program, t, spec)
+    if info:
+        return float("nan"), np.full(len(params) + 1, np.nan), info
+    z = solve_triangular(L, y, lower=True, check_finite=False)
+    lm = float(-0.5 * z @ z - np.log(np.diag(L)).sum() - 0.5 * n * math.log(2 * math.pi))
+    alpha = solve_triangular(L, z, lower=True, trans="T", check_finite=False)
+    kinv, pinfo = lapack.dpotri(L, lower=1, overwrite_c=0)
+    if pinfo:
+        return float("nan"), np.full(len(params) + 1, np.nan), int(pinfo)
+    kinv = np.tril(kinv) + np.tril(kinv, -1).T
+    Q = 0.5 * (np.outer(alpha, alpha) - kinv)
+    g = []
+    _eval_adjoint(rpn_to_tree(ops, params), t[:, None], t[None, :], sp, Q, g)
+    g.append(float(np.trace(Q)))
+    return lm, np.array(g), 0
+
+
 def weights_normalize(logw):
     logw = np.asarray(logw, dtype=np.float64)
     ok = np.isfinite(logw)             # a failed particle (-inf / NaN) carries weight 0

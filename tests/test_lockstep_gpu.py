@@ -21,7 +21,9 @@ EPS = 2.220446049250313e-16
 def eng():
     import __graft_entry__ as ge
     ge.build()
-    return autogp.HipEngine(0)
+    e = autogp.HipEngine(0)
+    yield e
+    e.ctx.close()
 
 
 class _Counting:

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 def eng():
     import __graft_entry__ as ge
     ge.build()
-    return autogp.HipEngine(0)
+    e = autogp.HipEngine(0)
+    yield e
+    e.ctx.close()
 
 
 def test_fit_and_forecast_shapes(eng):

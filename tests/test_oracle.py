@@ -119,6 +119,23 @@ def test_gradient_against_finite_differences(golden):
         assert np.max(np.abs(g - gfd) / (np.abs(gfd) + 1e-4 * np.max(np.abs(gfd)) + 1e-8)) < 2e-4
 
 
+def test_numpy_reverse_mode_gradient_equals_the_c_forward_mode_gradient(golden):
+    """Two independently written gradients — numpy: one reverse sweep of the tree contracted with
+    (alpha alpha' - K^-1) / 2; C: forward mode per parameter — on every golden case that carries
+    one, under the case's own formula variants."""
+    seen = 0
+    for c in golden["cases"]:
+        if "grad" not in c:
+            continue
+        prog = prog_of(c)
+        lm, g, info = oracle_np.logml_grad(prog, c["t"], c["y"], c["spec"])
+        assert info == 0
+        assert abs(lm - c["logml"]) <= 1e-11 * abs(c["logml"])
+        assert nerr(g, c["grad"]) < max(1e-10, 50 * 2.2e-16 * c.get("cond", 1.0)), c["name"]
+        seen += 1
+    assert seen >= 10
+
+
 def test_weights_normalize():
     lw = np.array([-1000.0, -1001.0, -1002.5, -999.0])
     w, ess, ln = oracle_c.weights_normalize(lw)
