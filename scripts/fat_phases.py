@@ -1,10 +1,13 @@
 """Where the time of a fat step goes, wave by wave (diagnostic; not part of the product).
 
-Needs the diagnostic build (phase stamps compiled in; libngp.so never has them):
+Runs on the DIAGNOSTIC library: the product's sources linked with scripts/stamps/ngp_stamps.hip,
+which instantiates the column-sweep kernels (nowcastautogp_amd/csrc/ngp_col_kernels.h) with a
+stamping probe and takes the place of the product's weak NoProbe launchers.  libngp.so never
+contains any of it.  This script builds build/libngp_stamps.so itself when it is missing or stale:
 
-    cd nowcastautogp_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
-        -DNGP_PHASE_STAMPS -o ../libngp_stamps.so ngp_kernels.hip ngp_api.hip
     gpurun -- python3 scripts/fat_phases.py 15 16        # block column j, particles (x 200 scenarios)
+    gpurun -- python3 scripts/fat_phases.py -17 16       # thin step of column 17
+    gpurun -- python3 scripts/fat_phases.py 1016 16      # chol_diag of column 16
 
 Every wave of the fat launch of block column j records 100-MHz timestamps (start, first chunk done,
 half of the k-loop, k-loop done, M strips staged, epilogue issued, stores retired) and the CU/SIMD it
@@ -16,7 +19,25 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["NGP_LIB"] = os.path.join(ROOT, "nowcastautogp_amd", "libngp_stamps.so")
+STAMPS_LIB = os.path.join(ROOT, "build", "libngp_stamps.so")
+
+
+def build_stamps_lib():
+    import subprocess
+    csrc = os.path.join(ROOT, "nowcastautogp_amd", "csrc")
+    srcs = [os.path.join(csrc, "ngp_kernels.hip"), os.path.join(csrc, "ngp_api.hip"),
+            os.path.join(ROOT, "scripts", "stamps", "ngp_stamps.hip")]
+    deps = srcs + [os.path.join(csrc, h) for h in ("ngp_col_kernels.h", "ngp_mfma.h", "ngp_internal.h")]
+    if os.path.exists(STAMPS_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(STAMPS_LIB)
+                                          for d in deps):
+        return
+    os.makedirs(os.path.dirname(STAMPS_LIB), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-fPIC", "-shared", "-o", STAMPS_LIB] + srcs, cwd=csrc)
+
+
+build_stamps_lib()
+os.environ["NGP_LIB"] = STAMPS_LIB
 import numpy as np
 
 from nowcastautogp_amd import _lib
