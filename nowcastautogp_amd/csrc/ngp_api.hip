@@ -576,12 +576,24 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
         tm.run(1, bc * ((double)NB * NB * kd + (double)NB * NB * NB / 3.0),
                bc * 8.0 * (NB * kd + 2.0 * NB * NB),
                [&] { launch_chol_diag(g, p, bc, jj, k0_diag, s); });
-        const double rows = (double)(g.n0 - (jj + 1) * NB) + nrows_aux;
+        // rows that take part and the k-products they carry.  Gradient jobs (aux rows [I ; y']):
+        // identity tile a joins from block column a on and its k-loop starts at 64 a — the kernels
+        // skip the rest, so it is not counted either
+        double rows = (double)(g.n0 - (jj + 1) * NB) + nrows_aux;
         const double kc = k - k0_col;
-        double fl = rows * (2.0 * NB * kc + (double)NB * NB);
-        double by = 8.0 * (rows * kc + NB * kc + 2.0 * rows * NB);
+        double rows_kc = rows * kc;
+        if (g.aux_identity) {
+            rows = (double)(g.n0 - (jj + 1) * NB) + (double)(g.naux - g.n0);   // main rows + y'
+            rows_kc = rows * kc;
+            for (int a = 0; a <= jj && a < g.nb0; ++a) {
+                rows += NB;
+                rows_kc += NB * std::max(0.0, k - std::max((double)k0_col, (double)a * NB));
+            }
+        }
+        double fl = 2.0 * NB * rows_kc + rows * (double)NB * NB;
+        double by = 8.0 * (rows_kc + NB * kc + 2.0 * rows * NB);
         if (fat) {  // + column jj+1 partial sums from the same rows
-            fl += rows * 2.0 * NB * k;
+            fl += 2.0 * NB * rows_kc;
             by += 8.0 * (NB * k + 2.0 * rows * NB);
         }
         // class 0: the LDS-DMA kernel of the fat steps (the dominant kernel, the roofline figure);
@@ -1567,7 +1579,9 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         p.qpts = (const int32_t *)d_q;
         p.dtab = (double *)d_dtab;
         if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
-        tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + (double)g.naux * g.n0),
+        // K's lower blocks, the y' tile row and the zero blocks (a, a-1): the identity block of
+        // the aux rows is synthesised by the column kernels, not written
+        tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + 2.0 * NB * (double)g.n0),
                [&] { launch_fill(g, p, bc, sp, s); });
         factor_chunk(lane_of(c), g, p, bc, tm);
         const double n3 = (double)g.n0 * g.n0 * g.n0;

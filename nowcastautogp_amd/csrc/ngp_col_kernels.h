@@ -415,12 +415,15 @@ __device__ __forceinline__ void stage_mstrips(double *lds_m, const double *mstri
 // indexing) and the largest magnitude of the tile to *tmax_out — the fat steps of later columns
 // decide from those maxima which tile products may run on the fp32 matrix cores.
 // probe slots 12 + 3 it .. 14 + 3 it: K' of pass `it` arrived, product + LDS done, stores issued
-template <bool SHADOW = false, class Probe = NoProbe>
+// SYNTH (gradient jobs): the identity block of the aux rows [I ; y'] is never written to memory
+// by the fill; a tile of it that no step has touched yet is synthesised here instead of read —
+// synth = 1: zeros, 2: the identity (the tile on the block diagonal), 0: read as usual.
+template <bool SHADOW = false, bool SYNTH = false, class Probe = NoProbe>
 __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], double *Lr,
                                                     const double *lds_m, long ld, int kmax,
                                                     int lane, double *buf, Probe &probe,
                                                     float *Lr32 = nullptr,
-                                                    float *tmax_out = nullptr) {
+                                                    float *tmax_out = nullptr, int synth = 0) {
     double amax = 0.0;
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;          // row of S' inside a 16-tile
@@ -433,6 +436,12 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * it + ((n16 + 4 * r) & 15);
+                if constexpr (SYNTH) {
+                    if (synth) {
+                        kv[jt][r] = (synth == 2 && i == 16 * jt + jj0) ? 1.0 : 0.0;
+                        continue;
+                    }
+                }
                 kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
             }
     };
@@ -506,14 +515,26 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
 // owns in a 16-row group are loaded together and the next group is requested before this one is
 // written back: written as `*e -= x` per element, hipcc orders every load behind the previous
 // store (64 dependent round trips per tile: 35 us of a fat workgroup's 270, scripts/fat_phases.py).
+// fresh (gradient jobs): the tile is an untouched zero tile of the identity block — nothing is read
 __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, int c0,
-                                                       const double (*acc4)[4][4], int lane) {
+                                                       const double (*acc4)[4][4], int lane,
+                                                       bool fresh = false) {
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;
     double *base = rows + c0 + jj0;
     long roff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) roff[r] = (long)((n16 + 4 * r) & 15) * ld;
+    if (fresh) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    base[(long)(16 * it) * ld + roff[r] + 16 * jt] = -acc4[jt][it][r];
+        return;
+    }
     double v[2][4][4];
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
@@ -553,7 +574,10 @@ __device__ __forceinline__ long tmax_index(const JobGeom &g, int row_tile, int c
 }
 
 // THIN and FULL steps: direct operand loads (short k-loops), one row tile per wave.
-template <bool MIXED>
+// IDENT (gradient jobs, aux rows [I ; y']): identity tile a joins from block column a on, its
+// k-loop starts at 64 a, and a tile of the identity block that no step has written yet is
+// synthesised, not read (the fill leaves the identity block out).
+template <bool MIXED, bool IDENT = false>
 __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                           ColStep st) {
     __shared__ __attribute__((aligned(16))) char epi[EPI_LDS_BYTES];
@@ -570,11 +594,15 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     // gradient jobs: aux rows are [I ; y'], so W = X L^-T is block upper triangular — identity
     // tile a is zero left of block column a (skip it while a > j) and its k-loop starts at 64 a
     int kbeg = st.k0;
-    if (g.aux_identity && valid && tile >= st.nmain) {
-        const int a = tile - st.nmain;
-        if (a < g.nb0) {
-            if (a > st.j) valid = false;
-            else if (a * NB > kbeg) kbeg = a * NB;
+    int synth = 0;
+    if constexpr (IDENT) {
+        if (valid && tile >= st.nmain) {
+            const int a = tile - st.nmain;
+            if (a < g.nb0) {
+                if (a > st.j) valid = false;
+                else if (a * NB > kbeg) kbeg = a * NB;
+                synth = (a == st.j) ? 2 : 1;   // FULL step: the tile has not been touched
+            }
         }
     }
 
@@ -612,9 +640,10 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
             p.L32 + (long)item * g.item_stride + rowbase * ld,
             p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
     } else {
-        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
-                            reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES),
-                            probe);
+        solve_and_store_lds<false, IDENT>(
+            acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
+            reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES), probe, nullptr,
+            nullptr, synth);
     }
 }
 
@@ -629,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
 // LDS: M strips 32 KiB | panel block 32 KiB (64 rows x 512 B; 16-byte piece p of row r sits in
 // slot p ^ (r & 7), swizzled on the source address), reused for the per-wave epilogue tiles.
 // ---------------------------------------------------------------------------------------
-template <bool MIXED, class Probe = NoProbe>
+template <bool MIXED, class Probe = NoProbe, bool IDENT = false>
 __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                                ColStep st) {
     constexpr int A_BYTES = NB * NB * 8;
@@ -651,11 +680,15 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
     // gradient jobs: identity tile a is zero left of block column a — tile a == j has nothing to
     // subtract (its k-range would start at 64 j), tiles a > j are still zero
     bool update = true;
-    if (g.aux_identity && valid && tile >= st.nmain) {
-        const int a = tile - st.nmain;
-        if (a < g.nb0) {
-            if (a > j) valid = false;
-            else if (a * NB > k0) update = false;
+    int synth = 0;     // the tile on the block diagonal (a == j) has not been touched: identity
+    if constexpr (IDENT) {
+        if (valid && tile >= st.nmain) {
+            const int a = tile - st.nmain;
+            if (a < g.nb0) {
+                if (a > j) valid = false;
+                else if (a * NB > k0) update = false;
+                if (a == j) synth = 2;
+            }
         }
     }
     const long ld = g.ld;
@@ -737,8 +770,8 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
             p.L32 + (long)item * g.item_stride + rowbase * ld,
             p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
     } else {
-        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane, buf,
-                            probe);
+        solve_and_store_lds<false, IDENT>(acc4, Lr, reinterpret_cast<const double *>(smem), ld,
+                                          kmax, lane, buf, probe, nullptr, nullptr, synth);
     }
     probe.mark_after(5, lane);
     probe.drain();
@@ -784,7 +817,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
-template <bool MIXED, class Probe = NoProbe>
+template <bool MIXED, class Probe = NoProbe, bool IDENT = false>
 __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                                ColStep st) {
     // 32 LDS-DMA blocks (8 rows x 128 B) per buffer, each followed by a 128-B gap: row groups of
@@ -821,7 +854,12 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     // tiles of a workgroup share the staged k-range, so it starts at the smaller of their starts;
     // a workgroup whose tiles are all still zero leaves before the first barrier.
     int kbeg = st.k0;
-    if (!MIXED && g.aux_identity && tile0 >= st.nmain) {
+    int synth = 0;     // identity-block tiles are untouched when a fat step reaches them
+    if constexpr (IDENT) {
+        const int a = tile - st.nmain;
+        if (tile < st.ntiles && a >= 0 && a < g.nb0) synth = (a == j) ? 2 : 1;
+    }
+    if (IDENT && tile0 >= st.nmain) {
         // workgroup-uniform: first k of each of the two tiles (kmax + 1: nothing to do)
         int kfirst = kmax + 1;
 #pragma unroll
@@ -1125,7 +1163,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 
     double *Lr = Lit + tile_row0(tile) * ld;
     if (col) {
-        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane);
+        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane, IDENT && synth != 0);
     } else if constexpr (MIXED) {
         const int rt = (tile < st.nmain) ? j + 1 + tile : g.nb0 + (tile - st.nmain);
         solve_and_store_lds<true>(
@@ -1134,9 +1172,10 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
             p.L32 + (long)item * g.item_stride + tile_row0(tile) * ld,
             p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
     } else {
-        solve_and_store_lds(acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
-                            reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES),
-                            probe);
+        solve_and_store_lds<false, IDENT>(
+            acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
+            reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES), probe, nullptr,
+            nullptr, synth);
     }
     probe.mark(5);
     probe.drain();       // stores retired (vmcnt(0))
@@ -1167,30 +1206,34 @@ void launch_chol_col_t(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int 
     st.ntiles = st.nmain + g.naux_pad / NB;
     if (st.ntiles <= 0) return;
     const int bpad = (Bc + 7) / 8 * 8;
+    const dim3 blk(256);
     if (mode == COL_FAT) {
         st.groups = (st.ntiles + 1) / 2;
+        const dim3 grid(st.groups * bpad);
         if (mixed)
-            hipLaunchKernelGGL((chol_col_glds_kernel<true, Probe>), dim3(st.groups * bpad), dim3(256), 0, s,
-                               g, p, Bc, st);
+            hipLaunchKernelGGL((chol_col_glds_kernel<true, Probe>), grid, blk, 0, s, g, p, Bc, st);
+        else if (g.aux_identity)
+            hipLaunchKernelGGL((chol_col_glds_kernel<false, Probe, true>), grid, blk, 0, s, g, p, Bc, st);
         else
-            hipLaunchKernelGGL((chol_col_glds_kernel<false, Probe>), dim3(st.groups * bpad), dim3(256), 0, s,
-                               g, p, Bc, st);
+            hipLaunchKernelGGL((chol_col_glds_kernel<false, Probe>), grid, blk, 0, s, g, p, Bc, st);
     } else if (mode == COL_THIN && k0 == j * NB - NB && j > 0) {
         st.groups = (st.ntiles + 3) / 4;
+        const dim3 grid(st.groups * bpad);
         if (mixed)
-            hipLaunchKernelGGL((chol_col_thin_kernel<true, Probe>), dim3(st.groups * bpad), dim3(256), 0, s,
-                               g, p, Bc, st);
+            hipLaunchKernelGGL((chol_col_thin_kernel<true, Probe>), grid, blk, 0, s, g, p, Bc, st);
+        else if (g.aux_identity)
+            hipLaunchKernelGGL((chol_col_thin_kernel<false, Probe, true>), grid, blk, 0, s, g, p, Bc, st);
         else
-            hipLaunchKernelGGL((chol_col_thin_kernel<false, Probe>), dim3(st.groups * bpad), dim3(256), 0,
-                               s, g, p, Bc, st);
+            hipLaunchKernelGGL((chol_col_thin_kernel<false, Probe>), grid, blk, 0, s, g, p, Bc, st);
     } else {
         st.groups = (st.ntiles + 3) / 4;
+        const dim3 grid(st.groups * bpad);
         if (mixed)
-            hipLaunchKernelGGL(chol_col_kernel<true>, dim3(st.groups * bpad), dim3(256), 0, s, g, p,
-                               Bc, st);
+            hipLaunchKernelGGL(chol_col_kernel<true>, grid, blk, 0, s, g, p, Bc, st);
+        else if (g.aux_identity)
+            hipLaunchKernelGGL((chol_col_kernel<false, true>), grid, blk, 0, s, g, p, Bc, st);
         else
-            hipLaunchKernelGGL(chol_col_kernel<false>, dim3(st.groups * bpad), dim3(256), 0, s, g,
-                               p, Bc, st);
+            hipLaunchKernelGGL(chol_col_kernel<false>, grid, blk, 0, s, g, p, Bc, st);
     }
 }
 

@@ -144,8 +144,13 @@ __global__ __launch_bounds__(256) void fill_kernel(JobGeom g, ChunkPtrs p, int n
         c = tile - r * (r + 1) / 2;
     } else {
         const int a = tile - ntri;
-        r = a / g.nb0;   // aux tile row
-        c = a % g.nb0;
+        if (g.aux_identity) {   // only the y' tile row and the zero blocks (a, a-1), see launch_fill
+            r = a < g.nb0 ? g.nb0 : a - g.nb0 + 1;
+            c = a < g.nb0 ? a : a - g.nb0;
+        } else {
+            r = a / g.nb0;   // aux tile row
+            c = a % g.nb0;
+        }
         aux = true;
     }
     // thread = (column pair tx, 8-row group ty): two adjacent columns per thread -> 16-byte stores
@@ -433,8 +438,13 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
         c = tile - r * (r + 1) / 2;
     } else {
         const int a = tile - ntri;
-        r = a / g.nb0;
-        c = a % g.nb0;
+        if (g.aux_identity) {   // only the y' tile row and the zero blocks (a, a-1), see launch_fill
+            r = a < g.nb0 ? g.nb0 : a - g.nb0 + 1;
+            c = a < g.nb0 ? a : a - g.nb0;
+        } else {
+            r = a / g.nb0;   // aux tile row
+            c = a % g.nb0;
+        }
         aux = true;
     }
     // thread = (column pair tx, 8-row group ty): two adjacent columns per thread -> 16-byte stores
@@ -1586,8 +1596,10 @@ __global__ __launch_bounds__(256) void grad_alpha_kernel(JobGeom g, const double
     if (a > g.n0) return;
     const double *W = L + (long)item * g.item_stride + (long)g.n0 * g.ld;
     const double *wa = W + (long)a * g.ld, *z = W + (long)g.n0 * g.ld;
+    // W is block upper triangular and what lies left of a row's diagonal block is never written
+    // (nor read): row a starts at its own block column
     double s = 0.0;
-    for (int k = lane; k < g.n0; k += 64) s += wa[k] * z[k];
+    for (int k = (a < g.n0 ? (a / NB) * NB : 0) + lane; k < g.n0; k += 64) s += wa[k] * z[k];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0) {
@@ -1912,6 +1924,256 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
             red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
+// The lattice contraction for trees of at most NL leaves (2 NL - 1 nodes) with NOTHING
+// runtime-indexed in private memory.  The runtime-indexed gacc[] of the kernel above goes to scratch
+// (784 B per lane: 58 MB of HBM traffic per item and call, and every `gacc[po] +=` a dependent
+// load-add-store); indexing the accumulators by node slot instead needs 3 x 16 of them and the
+// unrolled sweeps then keep ~225 VGPRs + scratch.  Here the workgroup first splits the program
+// into its LEAVES and its BINARY nodes (in postfix order each, which is a topological order), and
+// both sweeps run leaf list / binary list separately, unrolled over the list ordinal:
+//     forward:  leaves -> vals[node];  binaries ascending: vals[node] = op(vals[first], vals[node-1])
+//     reverse:  vals[root] = w;  binaries descending: the adjoints of the two operands overwrite
+//               their values (every node has one parent: its value is dead once the parent is
+//               done);  leaves: a = vals[node], accumulate
+// so the accumulators are ga[leaf ordinal][3] and gcp[binary ordinal][2] — 38 doubles for 15
+// nodes, all static — and one LDS array [node][thread] carries values, then adjoints.
+template <int NL>
+__global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, ChunkPtrs p,
+                                                                  const double *Kinv,
+                                                                  const double *alpha,
+                                                                  double *partials, int ntri,
+                                                                  int split, DevSpec sp) {
+    constexpr int NBIN = NL - 1, NN = 2 * NL - 1;
+    __shared__ DevProgram P;
+    __shared__ double red[4][NGP_MAX_PARAMS + 1];
+    __shared__ double cst[NN][2];
+    __shared__ double vals[NN][256];
+    __shared__ unsigned leaf_dec[NL], bin_dec[NBIN > 0 ? NBIN : 1];
+    const int item = blockIdx.y, tile = blockIdx.x / split, sub = blockIdx.x % split;
+    const int tid = threadIdx.x;
+    const int nrows = 16 / split;
+    load_program(&P, p.progs + item);
+    __syncthreads();
+    if (tid < 64) {   // one wave: node i -> its list and its constants
+        const int i = tid;
+        const bool live = i < P.n_ops;
+        const int op = live ? P.ops[i] : 0, po = live ? P.poff[i] : 0;
+        const bool leaf = live && op < NGP_OP_PLUS;
+        const unsigned long long lm = __ballot(leaf), bm = __ballot(live && !leaf);
+        const unsigned long long below = (1ull << i) - 1ull;
+        // node | opcode | parameter offset | table / sigmoid slot; binaries: first operand in the top byte
+        if (leaf)
+            leaf_dec[__popcll(lm & below)] =
+                (unsigned)i | ((unsigned)op << 5) | ((unsigned)po << 9) | ((unsigned)P.slot[i] << 17);
+        else if (live)
+            bin_dec[__popcll(bm & below)] = (unsigned)i | ((unsigned)op << 5) | ((unsigned)po << 9) |
+                                            ((unsigned)P.slot[i] << 17) | ((unsigned)P.first[i] << 25);
+        if (i < NN) {
+            double c0 = 0.0, c1 = 0.0;
+            if (op == NGP_OP_SQEXP) {
+                const double l = P.params[po], am = P.params[po + 1];
+                c0 = am * (sp.se_form ? 0.5 / (l * l) : 1.0 / (l * l * l));
+            } else if (op == NGP_OP_GAMMAEXP) {
+                c0 = P.params[po + 2] * P.params[po + 1] / P.params[po];
+                c1 = P.params[po + 2];
+            } else if (op == NGP_OP_PERIODIC) {
+                const double l = P.params[po], per = P.params[po + 1], am = P.params[po + 2];
+                const double cq = sp.periodic_form ? 2.0 / l : 2.0 / (l * l);
+                c0 = am * (sp.periodic_form ? 2.0 / (l * l) : 4.0 / (l * l * l));
+                c1 = am * cq * 2.0 * M_PI / (per * per);
+            } else if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
+                c1 = 1.0 / P.params[po + 1];
+                c0 = sp.cp_form ? c1 : -c1;            // u = c0 (t - loc)
+            }
+            cst[i][0] = c0;
+            cst[i][1] = c1;
+        }
+    }
+    __syncthreads();
+    int r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+    while (r * (r + 1) / 2 > tile) --r;
+    const int c = tile - r * (r + 1) / 2;
+    const int tx = tid & 63, ty = tid >> 6;
+    const int col = c * NB + tx;
+    const int np = P.n_params;
+    const int nops = __builtin_amdgcn_readfirstlane(P.n_ops);
+    const int nl = (nops + 1) / 2, nbin = nops / 2;       // a binary tree: nl leaves, nl - 1 binaries
+    const int R = g.R, npts = g.npts;
+    const double *tab = p.tab + (long)item * g.maxstat * R;
+    const double *dt = p.dtab + (long)item * g.maxstat * 3 * R;
+    const double *sig = p.sig + (long)item * g.maxcp * npts;
+    unsigned ld_[NL], bd_[NBIN > 0 ? NBIN : 1];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) ld_[l] = (unsigned)__builtin_amdgcn_readfirstlane((int)leaf_dec[l]);
+#pragma unroll
+    for (int b = 0; b < NBIN; ++b) bd_[b] = (unsigned)__builtin_amdgcn_readfirstlane((int)bin_dec[b]);
+    auto f_node = [](unsigned d) { return (int)(d & 31u); };
+    auto f_op = [](unsigned d) { return (int)((d >> 5) & 15u); };
+    auto f_po = [](unsigned d) { return (int)((d >> 9) & 255u); };
+    auto f_slot = [](unsigned d) { return (int)((d >> 17) & 255u); };
+    auto f_first = [](unsigned d) { return (int)(d >> 25); };
+    double ga[NL][3], gcp[NBIN > 0 ? NBIN : 1][2];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) ga[l][0] = ga[l][1] = ga[l][2] = 0.0;
+#pragma unroll
+    for (int b = 0; b < NBIN; ++b) gcp[b][0] = gcp[b][1] = 0.0;
+    double gnoise = 0.0;
+    const double *Ki = Kinv + (long)item * g.n0 * g.n0;
+    const double *al = alpha + (long)item * g.n0;
+    if (col < g.n_real) {
+        const double t2 = p.t0[col], ac = al[col];
+        const int q2 = p.qpts[col];
+        for (int rr = 0; rr < nrows; ++rr) {
+            const int row = r * NB + ty * 16 + sub * nrows + rr;
+            if (row >= g.n_real || col > row) continue;
+            // nothing loop-invariant is to be hoisted out of this loop: with the sweeps unrolled
+            // hipcc would keep every node's parameters, constants and table addresses in VGPRs
+            // across the rows
+            asm volatile("" ::: "memory");
+            double w = al[row] * ac - Ki[(long)row * g.n0 + col];
+            if (row == col) w *= 0.5;
+            const double t1 = p.t0[row];
+            const double d = fabs(t1 - t2);
+            const int dq = abs(p.qpts[row] - q2);
+            // ---- forward: leaves, then binary nodes in postfix order
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                if (l >= nl) break;
+                const int op = f_op(ld_[l]), po = f_po(ld_[l]);
+                double v;
+                if (op == NGP_OP_CONSTANT) v = P.params[po];
+                else if (op == NGP_OP_LINEAR)
+                    v = P.params[po + 1] + P.params[po + 2] * (t1 - P.params[po]) * (t2 - P.params[po]);
+                else v = tab[(long)f_slot(ld_[l]) * R + dq];
+                vals[f_node(ld_[l])][tid] = v;
+            }
+#pragma unroll
+            for (int b = 0; b < NBIN; ++b) {
+                if (b >= nbin) break;
+                const int op = f_op(bd_[b]), nd = f_node(bd_[b]);
+                const double x = vals[f_first(bd_[b])][tid], y = vals[nd - 1][tid];
+                double v;
+                if (op == NGP_OP_PLUS) v = x + y;
+                else if (op == NGP_OP_TIMES) v = x * y;
+                else {
+                    const double kl = (op == NGP_OP_CHANGEPOINT) ? x : y;
+                    const double kr = (op == NGP_OP_CHANGEPOINT) ? y : x;
+                    const double g1 = sig[(long)f_slot(bd_[b]) * npts + row];
+                    const double g2 = sig[(long)f_slot(bd_[b]) * npts + col];
+                    v = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
+                }
+                vals[nd][tid] = v;
+            }
+            // ---- reverse: the root's adjoint is w; adjoints overwrite values on the way down
+            vals[nops - 1][tid] = w;
+#pragma unroll
+            for (int b = NBIN - 1; b >= 0; --b) {
+                if (b >= nbin) continue;
+                const int op = f_op(bd_[b]), nd = f_node(bd_[b]), fi = f_first(bd_[b]);
+                const double a = vals[nd][tid];
+                const double x = vals[fi][tid], y = vals[nd - 1][tid];
+                double ax, ay;   // adjoints of the first-evaluated and the second operand
+                if (op == NGP_OP_PLUS) {
+                    ax = a; ay = a;
+                } else if (op == NGP_OP_TIMES) {
+                    ax = a * y; ay = a * x;
+                } else {
+                    const bool nat = (op == NGP_OP_CHANGEPOINT);
+                    const double kl = nat ? x : y, kr = nat ? y : x;
+                    const int po = f_po(bd_[b]);
+                    const double loc = P.params[po];
+                    const double us = cst[nd][0], isc = cst[nd][1];   // u = us (t - loc), 1 / scale
+                    const double u1 = us * (t1 - loc), u2 = us * (t2 - loc);
+                    const double g1 = sig[(long)f_slot(bd_[b]) * npts + row];
+                    const double g2 = sig[(long)f_slot(bd_[b]) * npts + col];
+                    const double q1 = 2.0 * g1 * (1.0 - g1), q2_ = 2.0 * g2 * (1.0 - g2);
+                    const double d1l = -q1 * us, d2l = -q2_ * us;
+                    const double d1s = -q1 * u1 * isc, d2s = -q2_ * u2 * isc;
+                    gcp[b][0] += a * (d1l * kl * g2 + g1 * kl * d2l - d1l * kr * (1.0 - g2) -
+                                      (1.0 - g1) * kr * d2l);
+                    gcp[b][1] += a * (d1s * kl * g2 + g1 * kl * d2s - d1s * kr * (1.0 - g2) -
+                                      (1.0 - g1) * kr * d2s);
+                    const double al_ = a * g1 * g2, ar_ = a * (1.0 - g1) * (1.0 - g2);
+                    ax = nat ? al_ : ar_;
+                    ay = nat ? ar_ : al_;
+                }
+                vals[fi][tid] = ax;
+                vals[nd - 1][tid] = ay;
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                if (l >= nl) break;
+                const int op = f_op(ld_[l]), po = f_po(ld_[l]), nd = f_node(ld_[l]);
+                const double a = vals[nd][tid];
+                if (op == NGP_OP_CONSTANT) {
+                    ga[l][0] += a;
+                } else if (op == NGP_OP_LINEAR) {
+                    const double cc = P.params[po], a1 = t1 - cc, a2 = t2 - cc;
+                    ga[l][0] += a * P.params[po + 2] * (-a1 - a2);
+                    ga[l][1] += a;
+                    ga[l][2] += a * a1 * a2;
+                } else {
+                    const double *d0 = dt + (long)f_slot(ld_[l]) * 3 * R + dq;
+                    const double e = d0[0];
+                    const double c0 = cst[nd][0], c1 = cst[nd][1];
+                    if (op == NGP_OP_SQEXP) {
+                        ga[l][0] += a * e * d * d * c0;
+                        ga[l][1] += a * e;
+                    } else if (op == NGP_OP_GAMMAEXP) {
+                        ga[l][0] += a * c0 * d0[R];
+                        ga[l][1] -= a * c1 * d0[2 * R];
+                        ga[l][2] += a * e;
+                    } else {
+                        ga[l][0] += a * c0 * d0[R];
+                        ga[l][1] += a * c1 * d0[2 * R];
+                        ga[l][2] += a * e;
+                    }
+                }
+            }
+            if (row == col) gnoise += w;   // d K / d noise = I (w already carries the 1/2)
+        }
+    }
+    // ---- deterministic reduction: wave shuffles per (node, parameter), then the four waves in order
+    const int lane = tid & 63, wave = tid >> 6;
+    auto wave_sum = [&](double v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        return v;
+    };
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        if (l >= nl) break;
+        const int op = f_op(ld_[l]);
+        const int cnt = op == NGP_OP_CONSTANT ? 1 : (op == NGP_OP_SQEXP ? 2 : 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (k >= cnt) break;
+            const double v = wave_sum(ga[l][k]);
+            if (lane == 0) red[wave][f_po(ld_[l]) + k] = v;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NBIN; ++b) {
+        if (b >= nbin) break;
+        const int op = f_op(bd_[b]);
+        if (op != NGP_OP_CHANGEPOINT && op != OP_CP_SWAPPED) continue;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double v = wave_sum(gcp[b][k]);
+            if (lane == 0) red[wave][f_po(bd_[b]) + k] = v;
+        }
+    }
+    {
+        const double v = wave_sum(gnoise);
+        if (lane == 0) red[wave][np] = v;
+    }
+    __syncthreads();
+    if (tid <= np)
+        partials[((long)item * ntri * split + blockIdx.x) * (NGP_MAX_PARAMS + 1) + tid] =
+            red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 __global__ __launch_bounds__(128) void grad_reduce_kernel(JobGeom g, const DevProgram *progs,
                                                           const double *partials, const double *quad,
                                                           const double *logdet, double *grad,
@@ -2138,7 +2400,11 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
                  bool aux_only) {
     if (g.n0 == 0) return;
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
-    const int ntiles = ntri + (g.naux_pad / NB) * g.nb0;
+    // Gradient jobs (aux rows [I ; y']): the identity block is NOT written — the column kernels
+    // synthesise a tile of it the first time they meet it (chol_col*<.., IDENT>).  What is written:
+    // the tile row that carries y' and the zero blocks (a, a - 1) just left of the block diagonal,
+    // which the k-loops of a tile pair and of K^-1 = W W' read as part of their shared k-range.
+    const int ntiles = ntri + (g.aux_identity ? g.nb0 + (g.nb0 - 1) : (g.naux_pad / NB) * g.nb0);
     const int off = aux_only ? ntri : 0;
     if (g.lattice) {
         const long nwg = (long)(ntiles - off) * Bc;
@@ -2273,7 +2539,13 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
     if (g.lattice && p.dtab) {
         const int split = grad_contract_split(ntri, Bc);
         nparts = ntri * split;
-        if (g.maxops <= LDSV_OPS)
+        if (g.maxops <= 7)
+            hipLaunchKernelGGL(grad_contract_lists_kernel<4>, dim3(ntri * split, Bc), dim3(256),
+                               0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
+        else if (g.maxops <= 15)
+            hipLaunchKernelGGL(grad_contract_lists_kernel<8>, dim3(ntri * split, Bc), dim3(256),
+                               0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
+        else if (g.maxops <= LDSV_OPS)
             hipLaunchKernelGGL(grad_contract_lattice_kernel<true>, dim3(ntri * split, Bc), dim3(256),
                                0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
         else
