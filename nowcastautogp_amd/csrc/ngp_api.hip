@@ -303,6 +303,19 @@ struct ngp_ctx {
         cached_bytes += it->second;
         live.erase(it);
     }
+    // split-k fat steps of small chunks (ngp_col_kernels.h): grow-only, owned by the context
+    double *splitk_part = nullptr;
+    int splitk_items = 0;
+    ngp_status splitk_reserve(int items) {
+        if (items <= splitk_items) return NGP_OK;
+        void *a = nullptr;
+        if (alloc(&a, sizeof(double) * (size_t)items * SPLITK_SLOTS * 4 * 64 * 64))
+            return NGP_ERR_TOO_LARGE;
+        release(splitk_part);
+        splitk_part = (double *)a;
+        splitk_items = items;
+        return NGP_OK;
+    }
     // bytes a job's factor storage may take: 3/4 of what the device has free now plus what this
     // context's cache would give back (the figure of ngp_ctx_create goes stale as soon as another
     // context or a resident factor allocates)
@@ -533,8 +546,9 @@ struct EventTimer {  // HIP events on the launch stream, resolved after the job'
 struct Lane {
     hipStream_t main, side;
     hipEvent_t fork, join;
+    ngp_ctx *ctx;
 };
-inline Lane lane_of(ngp_ctx *c) { return Lane{c->stream, c->side, c->ev_fork, c->ev_join}; }
+inline Lane lane_of(ngp_ctx *c) { return Lane{c->stream, c->side, c->ev_fork, c->ev_join, c}; }
 
 // dinv_step != 0: block column jj writes / reads its M at p.dinv + jj * dinv_step (cached factor:
 // every M_j is kept); 0: one buffer reused by every step.
@@ -546,12 +560,18 @@ constexpr size_t MAX_CHUNK_ITEMS = 65535;   // gridDim.y
 // byte offsets: it must stay below 2 GiB (n <= 16,256 for value jobs, 11,520 for gradient jobs).
 inline bool item_too_large(int64_t item_stride) { return item_stride * 8 > (int64_t)0x7fffffff; }
 constexpr int MIXED_REORDER = 16;
+constexpr int AHEAD_EARLY_MAX_ITEMS = 512;
 void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int bc, EventTimer &tm,
                   size_t dinv_step = 0, const DevSpec *sp = nullptr, int32_t *order_buf = nullptr,
                   unsigned *order_prev = nullptr) {
     ChunkPtrs p0 = p_in;
     const bool mixed = sp != nullptr && p0.L32 != nullptr;
     hipStream_t s = ln.main;
+    // small chunks of long series: room for the split-k fat steps (chol_col_glds_kernel<.., SPLITK>);
+    // the buffer stays with the context
+    if (bc <= AHEAD_EARLY_MAX_ITEMS && !mixed && !g.aux_identity && g.nb0 >= 8 &&
+        ln.ctx->splitk_reserve(bc) == NGP_OK)
+        p0.splitk_part = ln.ctx->splitk_part;
     const double nrows_aux = (double)g.naux;
     bool ahead_pending = false;
     for (int jj = 0; jj < g.nb0; ++jj) {
@@ -573,6 +593,23 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
             (void)hipStreamWaitEvent(s, ln.join, 0);
             ahead_pending = false;
         }
+        // Small chunks (the 64-particle calls of a fit): the diag-ahead tile of this pair goes to
+        // the side stream BEFORE chol_diag / the fat step — everything it reads (rows of block
+        // jj + 2, columns < 64 jj) is final once column jj - 1 is.  Beside the fat step it has
+        // several hundred microseconds to hide in; launched after it (the large-batch order below)
+        // its single-wave k-loop outlasts chol_diag + the thin step from n ~ 1500 on and
+        // chol_diag(jj + 2) waits for it.  The order of launches does not change any result.
+        const bool ahead_early = bc <= AHEAD_EARLY_MAX_ITEMS;
+        auto launch_ahead = [&] {
+            (void)hipEventRecord(ln.fork, s);
+            (void)hipStreamWaitEvent(ln.side, ln.fork, 0);
+            // class 8: on the side stream
+            tm.run(8, bc * (double)NB * NB * k, bc * 8.0 * NB * k,
+                   [&] { launch_diag_ahead(g, p0, bc, jj, ln.side); }, ln.side);
+            (void)hipEventRecord(ln.join, ln.side);
+            ahead_pending = true;
+        };
+        if (ahead && jj > 0 && ahead_early) launch_ahead();
         tm.run(1, bc * ((double)NB * NB * kd + (double)NB * NB * NB / 3.0),
                bc * 8.0 * (NB * kd + 2.0 * NB * NB),
                [&] { launch_chol_diag(g, p, bc, jj, k0_diag, s); });
@@ -605,15 +642,9 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
             // order_buf comes from the caching allocator uninitialised
             if (launch_mixed_order(p0, order_prev, order_buf, bc, s)) p0.order = order_buf;
         }
-        if (ahead && jj > 0) {
-            (void)hipEventRecord(ln.fork, s);
-            (void)hipStreamWaitEvent(ln.side, ln.fork, 0);
-            // class 8: on the side stream, beside chol_diag(jj+1) / the thin step of jj+1
-            tm.run(8, bc * (double)NB * NB * k, bc * 8.0 * NB * k,
-                   [&] { launch_diag_ahead(g, p0, bc, jj, ln.side); }, ln.side);
-            (void)hipEventRecord(ln.join, ln.side);
-            ahead_pending = true;
-        }
+        // large chunks: beside chol_diag(jj+1) / the thin step of jj+1 (beside the fat step it
+        // cost more: profiles/r02/README.md)
+        if (ahead && jj > 0 && !ahead_early) launch_ahead();
     }
     if (ahead_pending) {
         (void)hipStreamWaitEvent(s, ln.join, 0);

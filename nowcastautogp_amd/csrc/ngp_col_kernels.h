@@ -7,6 +7,8 @@
 // instantiates the same kernels with a probe that records 100-MHz timestamps per wave
 // (scripts/fat_phases.py); nothing of it is compiled into libngp.so.
 #pragma once
+#include <algorithm>
+
 #include "ngp_mfma.h"
 
 namespace ngp {
@@ -563,6 +565,7 @@ struct ColStep {
     int nmain;    // main row tiles below the diagonal (r = j+1 ...); 0: aux tiles only
     int ntiles;   // nmain + aux tiles
     int groups;   // workgroups per item
+    int splits;   // fat steps of small batches: workgroups that share one tile pair's k-range (1: none)
     // mixed-precision jobs: a tile product runs in fp32 iff max|A| max|B| <= c32 (noise + jitter),
     // c32 = mixed_tau / (64 * 2^-24)
     double c32, jitter;
@@ -817,7 +820,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
-template <bool MIXED, class Probe = NoProbe, bool IDENT = false>
+//
+// SPLITK (small batches, late block columns): with a few dozen items a fat step of a late column is
+// a handful of workgroups per item, each with a k-loop of a thousand columns and more — a fraction
+// of the CUs busy for hundreds of microseconds (64 items at n = 2048, j = 30: 64 workgroups, 290 us
+// for 73 us of arithmetic).  st.splits workgroups then share one tile pair: each accumulates a
+// contiguous piece of the k-range and leaves its four accumulator tiles in p.splitk_part
+// (SPLITK = 1); a second launch with one workgroup per tile pair (SPLITK = 2) adds the pieces in
+// piece order and runs the epilogue.  (One launch with the last workgroup to arrive doing the sum
+// was measured first: the device-scope release it needs writes the L2 back per workgroup and cost
+// more than the second launch.)
+template <bool MIXED, class Probe = NoProbe, bool IDENT = false, int SPLITK = 0>
 __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                                ColStep st) {
     // 32 LDS-DMA blocks (8 rows x 128 B) per buffer, each followed by a 128-B gap: row groups of
@@ -831,8 +844,10 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 
     const int wg = blockIdx.x;
     const int xcd = wg & 7, idx = wg >> 3;       // blocks b and b+8 share an XCD (speed only)
-    const int slot = (idx / st.groups) * 8 + xcd;
-    const int grp = idx % st.groups;
+    const int per_item = SPLITK == 1 ? st.groups * st.splits : st.groups;
+    const int slot = (idx / per_item) * 8 + xcd;
+    const int grp = SPLITK == 1 ? (idx % per_item) / st.splits : idx % st.groups;
+    const int piece = SPLITK == 1 ? (idx % per_item) % st.splits : 0;
     if (slot >= Bc) return;                      // whole workgroup, before any barrier
     // mixed-precision batches: items with the most fp64 tile products are dispatched first
     // (mixed_order_kernel), so that a launch does not end on its slowest workgroups
@@ -950,8 +965,16 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
         }
     };
 
-    if constexpr (!MIXED) {
-        const int nchunks = (kmax - kbeg) / LDS_KC;
+    if constexpr (SPLITK == 2) {
+        // finishing launch of a split-k step: no k-loop, the pieces are added below
+    } else if constexpr (!MIXED) {
+        int nchunks = (kmax - kbeg) / LDS_KC;
+        if constexpr (SPLITK == 1) {   // this workgroup's piece of the k-range, whole chunks
+            const int per = (nchunks + st.splits - 1) / st.splits;
+            const int c0 = min(piece * per, nchunks);
+            nchunks = min(c0 + per, nchunks) - c0;
+            kbeg += c0 * LDS_KC;
+        }
         if (nchunks > 0) {
             stage(0, kbeg);
             __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
@@ -1152,6 +1175,48 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
             }
         }
     }
+    if constexpr (SPLITK == 1) {
+        // ---- hand in this piece: register e of lane l at [e][l] (512-byte rows) ----
+        double *mine = p.splitk_part +
+                       ((((long)slot * SPLITK_SLOTS + (long)grp * st.splits + piece) * 4 + wave) *
+                        (64 * 64)) + lane;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[((jt * 4 + it) * 4 + r) * 64] = acc4[jt][it][r];
+        return;
+    }
+    if constexpr (SPLITK == 2) {
+        // ---- the pieces of this tile pair, added piece by piece (ascending: deterministic), the
+        //      64 loads of a piece in flight together ----
+        const double *part = p.splitk_part +
+                             ((((long)slot * SPLITK_SLOTS + (long)grp * st.splits) * 4 + wave) *
+                              (64 * 64)) + lane;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc4[jt][it][r] = part[((jt * 4 + it) * 4 + r) * 64];
+        for (int q2 = 1; q2 < st.splits; ++q2) {
+            const double *pq = part + (long)q2 * 4 * (64 * 64);
+            double v[4][4][4];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[jt][it][r] = pq[((jt * 4 + it) * 4 + r) * 64];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int it = 0; it < 4; ++it)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc4[jt][it][r] += v[jt][it][r];
+        }
+    }
     // the staging buffers are free (every wave passed the k-loop's last barrier): M strips go to
     // LDS for both tiles of the workgroup
     static_assert(EPI_LDS_BYTES <= 2 * STAGE, "epilogue LDS must fit the stage buffers");
@@ -1210,7 +1275,24 @@ void launch_chol_col_t(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int 
     if (mode == COL_FAT) {
         st.groups = (st.ntiles + 1) / 2;
         const dim3 grid(st.groups * bpad);
-        if (mixed)
+        // small batches: late columns (few tile pairs, long k-loops) are cut along k so that the
+        // launch fills the chip; every piece keeps at least 8 staged chunks
+        int splits = 1;
+        if (!mixed && !g.aux_identity && p.splitk_part) {
+            const int nchunks = j * NB / LDS_KC;
+            // 384, not the 512 workgroups the chip holds: chol_diag's successor tile (diag_ahead,
+            // 4 waves of 224 VGPRs) is resident beside this launch and a second round costs more
+            // than the split saves (measured at 64 items, n = 2048)
+            splits = std::min(std::min(8, SPLITK_SLOTS / std::max(st.groups, 1)),
+                              std::min(nchunks / 8, 384 / std::max(st.groups * Bc, 1)));
+        }
+        st.splits = std::max(splits, 1);
+        if (splits >= 2) {
+            hipLaunchKernelGGL((chol_col_glds_kernel<false, Probe, false, 1>),
+                               dim3(st.groups * splits * bpad), blk, 0, s, g, p, Bc, st);
+            hipLaunchKernelGGL((chol_col_glds_kernel<false, Probe, false, 2>), grid, blk, 0, s, g, p,
+                               Bc, st);
+        } else if (mixed)
             hipLaunchKernelGGL((chol_col_glds_kernel<true, Probe>), grid, blk, 0, s, g, p, Bc, st);
         else if (g.aux_identity)
             hipLaunchKernelGGL((chol_col_glds_kernel<false, Probe, true>), grid, blk, 0, s, g, p, Bc, st);

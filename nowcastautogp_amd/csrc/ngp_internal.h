@@ -11,6 +11,7 @@ namespace ngp {
 constexpr int NB = 64;        // block-column width of the left-looking factorisation
 constexpr int TB = 16;        // MFMA tile edge (v_mfma_f64_16x16x4_f64)
 constexpr int DEV_STACK = 8;  // register-resident evaluation stack depth on the device
+constexpr int SPLITK_SLOTS = 16;   // (tile pair, piece) slots per item in ChunkPtrs::splitk_part
 
 // device opcode = host opcode, plus CP with its two operands in swapped stack order
 // (the host reorders children so the evaluation stack never exceeds DEV_STACK)
@@ -113,6 +114,8 @@ struct ChunkPtrs {
     int32_t n_fill_chain, n_fill_other, n_fill_single, fill_base;
     const int32_t *items; // refinement sweeps: the items (indices into the chunk) a launch works
                           // on, Bc = their count; null: all of them in order
+    // small chunks only (null otherwise): split-k fat steps, see chol_col_glds_kernel<.., SPLITK>
+    double       *splitk_part;  // [Bc][SPLITK_SLOTS][4 waves][64 x 64] accumulator tiles of the pieces
 };
 
 struct EpiPtrs {

@@ -2508,10 +2508,11 @@ bool launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int 
     return hipGetLastError() == hipSuccess;
 }
 
+constexpr int DIAG_AHEAD_SPLIT_K = 512;
 void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s) {
     // the split depends on the geometry only (not on the batch), so a given matrix is always
     // summed in the same order
-    if (j * NB >= 2048)
+    if (j * NB >= DIAG_AHEAD_SPLIT_K)
         hipLaunchKernelGGL(diag_ahead_kernel<4>, dim3(Bc), dim3(256), 0, s, g, p, j);
     else
         hipLaunchKernelGGL(diag_ahead_kernel<1>, dim3(Bc), dim3(64), 0, s, g, p, j);
