@@ -59,7 +59,9 @@ def F_logml_grad(n):
 
 
 KERNEL_OF_CLASS = {
-    "chol_col": "chol_col_glds_kernel<false>", "chol_col_mixed": "chol_col_glds_kernel<true>",
+    "chol_col": "chol_col_glds_kernel<false, NoProbe, false, 0>",
+    "chol_col_grad": "chol_col_glds_kernel<false, NoProbe, true, 0>",
+    "chol_col_mixed": "chol_col_glds_kernel<true, NoProbe, false, 0>",
     "chol_col_thin": "chol_col_thin_kernel / chol_col_kernel", "chol_diag": "chol_diag_kernel",
     "fill": "tables_kernel + fill_*_kernel", "grad_kinv": "grad_kinv_lds_kernel",
     "grad_contract": "grad_alpha / grad_contract_lattice / grad_reduce kernels",
@@ -77,7 +79,11 @@ def measured_traffic(config, kernel_key, items_per_launch):
         return None, None
     with open(path) as f:
         d = json.load(f)
-    k = d.get("kernels", {}).get(kernel_key)
+    ks = d.get("kernels", {})
+    # profiles of earlier rounds carry the kernel's earlier template signature
+    legacy = {"chol_col_glds_kernel<false, NoProbe, false, 0>": "chol_col_glds_kernel<false>",
+              "chol_col_glds_kernel<true, NoProbe, false, 0>": "chol_col_glds_kernel<true>"}
+    k = ks.get(kernel_key) or ks.get(legacy.get(kernel_key, ""))
     if not k:
         return None, path
     # the profiled job may cover fewer items per launch than this run's launches do (the PMC passes
@@ -573,7 +579,8 @@ def main():
         both_ms = fat["ms"] + thin["ms"]
         ach_both = (fat["flops"] + thin["flops"]) / (both_ms * 1e-3) * 1e-12 if both_ms else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if mixed else FP64_MFMA_PEAK_TFLOPS
-        kern_key = KERNEL_OF_CLASS.get(dom_key, dom_key)
+        kern_key = KERNEL_OF_CLASS.get("chol_col_grad" if (grad_mode and dom_key == "chol_col")
+                                       else dom_key, dom_key)
         npts = n + d if not grad_mode else n + d
         nb = (npts + 63) // 64 if grad_mode else npts // 64      # gradient jobs pad to a block
         fat_steps = nb // 2                                 # fat launches one item goes through

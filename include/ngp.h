@@ -112,7 +112,8 @@ enum {
     NGP_ERR_PROGRAM      = -2, /* malformed kernel program                     */
     NGP_ERR_TOO_LARGE    = -3, /* exceeds NGP_MAX_* or device memory           */
     NGP_ERR_NO_DEVICE    = -4, /* no HIP device / extension not usable         */
-    NGP_ERR_STATE        = -5  /* job used out of order                        */
+    NGP_ERR_STATE        = -5, /* job used out of order                        */
+    NGP_ERR_UNAVAILABLE  = -6  /* optional component missing (librccl.so)      */
 };
 
 typedef struct ngp_ctx ngp_ctx;
@@ -204,6 +205,31 @@ ngp_status ngp_weights_normalize(int32_t P, const double *logw,
  * are [D].  Column s equals ngp_weights_normalize on that column.                          */
 ngp_status ngp_weights_normalize_cols(int32_t P, int32_t D, const double *logw,
                                       double *w_norm, double *ess, double *log_norm);
+
+/* ---- the collective of the path, for hosts without a collective library --------------
+ * maybe_resample! is the only step of the hot path that needs every rank's particles
+ * (src/forecasting.jl:138-141): the P_total log-weights of every scenario.  A Julia host that
+ * runs one process per GPU has no torch.distributed; these entry points give it that one exchange
+ * over RCCL (xGMI inside a node).  librccl.so is opened at run time (no link-time dependency);
+ * without it every call returns NGP_ERR_UNAVAILABLE and the host must gather the weights itself
+ * and call ngp_weights_normalize_cols.
+ *   ngp_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other
+ *                        ranks by the host's own means (a file, a socket, MPI, Julia Distributed)
+ *   ngp_comm_create      collective over all ranks (ncclCommInitRank) on the context's device
+ *   ngp_weights_allgather_normalize
+ *        particles are block-partitioned over the ranks, remainder to the low ranks; this rank
+ *        passes its rows logw_local [P_local x D] (D scenario columns, row-major); ONE all-gather
+ *        of padded shards, then the normalisation of ngp_weights_normalize_cols on every rank:
+ *        w_local [P_local x D] (may be NULL), w_all [P_total x D] (may be NULL: what resampling
+ *        needs), ess [D], log_norm [D] (may be NULL).  Identical on every rank.                */
+typedef struct ngp_comm ngp_comm;
+ngp_status ngp_comm_unique_id(void *id128);
+ngp_status ngp_comm_create(ngp_ctx *ctx, const void *id128, int32_t rank, int32_t world,
+                           ngp_comm **out);
+void       ngp_comm_destroy(ngp_comm *comm);
+ngp_status ngp_weights_allgather_normalize(ngp_comm *comm, int32_t P_total, int32_t D,
+                                           const double *logw_local, double *w_local,
+                                           double *w_all, double *ess, double *log_norm);
 
 /* ---- staged execution (inputs resident in HBM before the timed region) ----
  * stage  : validate, allocate device buffers, copy inputs host -> device

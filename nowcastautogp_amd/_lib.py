@@ -27,7 +27,8 @@ SYMBOLS = (
     "ngp_ctx_create", "ngp_ctx_destroy", "ngp_set_spec", "ngp_get_spec", "ngp_default_spec",
     "ngp_strerror", "ngp_version", "ngp_kernel_check", "ngp_cov_batch", "ngp_logml_batch",
     "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
-    "ngp_weights_normalize_cols", "ngp_mixture_sample_indep",
+    "ngp_weights_normalize_cols", "ngp_mixture_sample_indep", "ngp_comm_unique_id", "ngp_comm_create",
+    "ngp_comm_destroy", "ngp_weights_allgather_normalize",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
     "ngp_job_mixed_stats", "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
     "ngp_factor_destroy", "ngp_mixture_sample", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
@@ -86,6 +87,10 @@ def load():
         "ngp_weights_normalize_cols": (i32, [i32, i32, f64p, f64p, f64p, f64p]),
         "ngp_mixture_sample_indep": (i32, [vp, i32, i32, i32, f64p, f64p, f64p, i32,
                                            C.POINTER(C.c_uint64), f64p, i32p, i32p]),
+        "ngp_comm_unique_id": (i32, [vp]),
+        "ngp_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "ngp_comm_destroy": (None, [vp]),
+        "ngp_weights_allgather_normalize": (i32, [vp, i32, i32, f64p, f64p, f64p, f64p, f64p]),
         "ngp_logml_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, C.POINTER(vp)]),
         "ngp_predict_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, i32, f64p, i32,
                                     C.POINTER(vp)]),
@@ -155,6 +160,53 @@ def weights_normalize_cols(logw):
     _chk(load().ngp_weights_normalize_cols(P, D, dptr(logw), dptr(w), dptr(ess), dptr(ln)),
          "ngp_weights_normalize_cols")
     return w, ess, ln
+
+
+NGP_ERR_UNAVAILABLE = -6
+
+
+def comm_unique_id() -> bytes:
+    """The 128-byte id rank 0 makes for ``Comm`` (``ngp_comm_unique_id``); raises ``NgpError`` with
+    status NGP_ERR_UNAVAILABLE when librccl is not installed."""
+    buf = C.create_string_buffer(128)
+    _chk(load().ngp_comm_unique_id(buf), "ngp_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """The C-ABI's own communicator over RCCL (``ngp_comm``): the one exchange of the path for
+    hosts without torch.distributed.  The Python mirror itself uses torch.distributed."""
+
+    def __init__(self, ctx: "Context", uid: bytes, rank: int, world: int):
+        h = C.c_void_p()
+        _chk(load().ngp_comm_create(ctx._h, C.c_char_p(uid), int(rank), int(world), C.byref(h)),
+             "ngp_comm_create")
+        self._h, self.ctx, self.rank, self.world = h, ctx, rank, world
+        ctx._children.add(self)
+
+    def allgather_normalize(self, logw_local, P_total: int):
+        """logw_local [P_local, D] -> (w_local [P_local, D], w_all [P_total, D], ess [D], log_norm [D])"""
+        lw = as_f64(logw_local)
+        if lw.ndim == 1:
+            lw = lw[:, None]
+        P_loc, D = lw.shape
+        w_loc, w_all = np.empty((P_loc, D)), np.empty((int(P_total), D))
+        ess, ln = np.empty(D), np.empty(D)
+        _chk(load().ngp_weights_allgather_normalize(self._h, int(P_total), D, dptr(lw), dptr(w_loc),
+                                                    dptr(w_all), dptr(ess), dptr(ln)),
+             "ngp_weights_allgather_normalize")
+        return w_loc, w_all, ess, ln
+
+    def close(self):
+        if self._h is not None and self.ctx._h is not None:
+            load().ngp_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _nullable(a: Optional[np.ndarray]):

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <mutex>
 #include <new>
@@ -367,6 +368,7 @@ extern "C" const char *ngp_strerror(ngp_status st) {
     case NGP_ERR_TOO_LARGE: return "problem exceeds a library limit or device memory";
     case NGP_ERR_NO_DEVICE: return "no usable HIP device";
     case NGP_ERR_STATE: return "job used out of order / entry point unavailable";
+    case NGP_ERR_UNAVAILABLE: return "optional component (librccl) is not available";
     default: break;
     }
     if (st > 0) return hipGetErrorString((hipError_t)st);
@@ -1758,6 +1760,140 @@ extern "C" ngp_status ngp_mixture_sample_indep(ngp_ctx *c, int32_t P, int32_t S,
                                                int32_t *info) {
     if (!seeds) return NGP_ERR_ARG;
     return mixture_sample_impl(c, P, S, m, w, mu, sigma, draws, 0, seeds, out, comp, info);
+}
+
+// ---------------------------------------------------------------------------------------
+// The one collective of the path (north_star: RCCL over xGMI only for the particle-weight
+// normalisation / resample reduction), for hosts that bring no collective library of their own
+// (the Julia shim; the Python mirror uses torch.distributed, whose "nccl" backend is this same
+// RCCL).  librccl is opened at run time: the library has no link-time dependency on it and the
+// entry points answer NGP_ERR_UNAVAILABLE when it is not installed.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct RcclUid { char internal[128]; };   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(RcclUid *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclUid, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    bool ok = false;
+};
+RcclApi load_rccl() {
+    RcclApi r;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) return r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+    return r;
+}
+const RcclApi &rccl() {
+    static const RcclApi api = load_rccl();
+    return api;
+}
+constexpr int RCCL_FLOAT64 = 8;   // ncclFloat64 (rccl.h)
+}  // namespace
+
+struct ngp_comm {
+    ngp_ctx *ctx = nullptr;
+    void *comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+extern "C" ngp_status ngp_comm_unique_id(void *id128) {
+    if (!id128) return NGP_ERR_ARG;
+    if (!rccl().ok) return NGP_ERR_UNAVAILABLE;
+    RcclUid uid{};
+    if (rccl().GetUniqueId(&uid) != 0) return NGP_ERR_UNAVAILABLE;
+    std::memcpy(id128, uid.internal, sizeof(uid.internal));
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_comm_create(ngp_ctx *c, const void *id128, int32_t rank, int32_t world,
+                                      ngp_comm **out) {
+    if (!c || !id128 || !out || world <= 0 || rank < 0 || rank >= world) return NGP_ERR_ARG;
+    *out = nullptr;
+    if (!rccl().ok) return NGP_ERR_UNAVAILABLE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    RcclUid uid{};
+    std::memcpy(uid.internal, id128, sizeof(uid.internal));
+    ngp_comm *m = new (std::nothrow) ngp_comm();
+    if (!m) return NGP_ERR_TOO_LARGE;
+    m->ctx = c;
+    m->rank = rank;
+    m->world = world;
+    if (rccl().CommInitRank(&m->comm, world, uid, rank) != 0) {
+        delete m;
+        return NGP_ERR_UNAVAILABLE;
+    }
+    *out = m;
+    return NGP_OK;
+}
+
+extern "C" void ngp_comm_destroy(ngp_comm *m) {
+    if (!m) return;
+    if (m->comm && rccl().ok) {
+        (void)hipSetDevice(m->ctx->device);
+        (void)rccl().CommDestroy(m->comm);
+    }
+    delete m;
+}
+
+extern "C" ngp_status ngp_weights_allgather_normalize(ngp_comm *m, int32_t P_total, int32_t D,
+                                                      const double *logw_local, double *w_local,
+                                                      double *w_all, double *ess,
+                                                      double *log_norm) {
+    if (!m || !logw_local || P_total <= 0 || D <= 0 || P_total < m->world) return NGP_ERR_ARG;
+    // block partition of the particles over the ranks, remainder to the low ranks (the partition
+    // nowcastautogp_amd.distributed.shard and the Julia shim use)
+    const int base = P_total / m->world, rem = P_total % m->world;
+    auto rows_of = [&](int r) { return base + (r < rem ? 1 : 0); };
+    auto first_of = [&](int r) { return r * base + std::min(r, rem); };
+    const int mine = rows_of(m->rank), pmax = base + (rem ? 1 : 0);
+    ngp_ctx *c = m->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // ragged shards: every rank sends pmax rows (its own, then padding)
+    const size_t cnt = (size_t)pmax * D;
+    void *d_send = nullptr, *d_recv = nullptr;
+    ngp_status st;
+    if ((st = c->alloc(&d_send, 8 * cnt)) || (st = c->alloc(&d_recv, 8 * cnt * (size_t)m->world))) {
+        c->release(d_send);
+        return st;
+    }
+    std::vector<double> h_all(cnt * (size_t)m->world);
+    hipError_t e = hipMemsetAsync(d_send, 0, 8 * cnt, s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_send, logw_local, 8 * (size_t)mine * D, hipMemcpyHostToDevice, s);
+    int rc = 0;
+    if (e == hipSuccess) rc = rccl().AllGather(d_send, d_recv, cnt, RCCL_FLOAT64, m->comm, s);
+    if (e == hipSuccess && rc == 0)
+        e = hipMemcpyAsync(h_all.data(), d_recv, 8 * h_all.size(), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(s);
+    c->release(d_send);
+    c->release(d_recv);
+    if (rc != 0) return NGP_ERR_UNAVAILABLE;
+    if (e != hipSuccess) return (ngp_status)e;
+    // compact the padded shards to [P_total x D], then the columns as ngp_weights_normalize_cols
+    std::vector<double> lw((size_t)P_total * D), wn((size_t)P_total * D);
+    for (int r = 0; r < m->world; ++r)
+        std::memcpy(lw.data() + (size_t)first_of(r) * D, h_all.data() + (size_t)r * cnt,
+                    8 * (size_t)rows_of(r) * D);
+    for (int sidx = 0; sidx < D; ++sidx)
+        weights_normalize_strided(P_total, lw.data() + sidx, D, wn.data() + sidx, D,
+                                  ess ? ess + sidx : nullptr, log_norm ? log_norm + sidx : nullptr);
+    if (w_all) std::memcpy(w_all, wn.data(), 8 * wn.size());
+    if (w_local)
+        std::memcpy(w_local, wn.data() + (size_t)first_of(m->rank) * D, 8 * (size_t)mine * D);
+    return NGP_OK;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """rocprofv3 --pmc counter_collection.csv files (one pass each for FETCH_SIZE and WRITE_SIZE) ->
-profiles/r02/pmc_<config>.json, the file bench.py reads its roofline.traffic from.
+profiles/rNN/pmc_<config>[_grad].json, the file bench.py reads its roofline.traffic from.
 
 Units are calibrated on the box, not assumed: the same passes contain ngp's stream_copy_kernel on
 1 GiB (reads 2^30 B, writes 2^30 B per launch); the factor that makes FETCH_SIZE / WRITE_SIZE of

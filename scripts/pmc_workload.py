@@ -1,6 +1,7 @@
 """The command the PMC passes profile: one HBM microbenchmark of known size (calibrates the
 FETCH_SIZE / WRITE_SIZE units on this box) followed by headline steps of bench.py's workload.
-Usage (under rocprofv3): python3 scripts/pmc_workload.py C3 [particles]"""
+Usage (under rocprofv3): python3 scripts/pmc_workload.py C3 [particles] [predict|grad]
+(grad: one logml + gradient call over the same items, bench.py --mode grad)"""
 import os
 import sys
 
@@ -16,13 +17,18 @@ from nowcastautogp_amd._abi import NGP_PREC_MIXED, default_spec
 from nowcastautogp_amd.synthetic import bench_items
 
 config = sys.argv[1] if len(sys.argv) > 1 else "C3"
-P = int(sys.argv[2]) if len(sys.argv) > 2 else None
+P = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] not in ("", "-") else None
+mode = sys.argv[3] if len(sys.argv) > 3 else "predict"
 ctx = _lib.Context(0)
 ctx.microbench_hbm(1 << 30)          # stream_write_kernel 2 x 1 GiB, stream_copy_kernel 2 x (1 + 1) GiB
 w, progs, Y, tt = bench_items(config, 0, None, P, None)
-if config == "C5":
-    ctx.set_spec(default_spec(NGP_PREC_MIXED))
-job = ctx.stage_predict(progs, tt, Y, w.t_new)
-job.run()
-out = job.fetch()
-print("items", len(progs), "failed", int(np.count_nonzero(out["info"])))
+if mode == "grad":
+    lm, g, info = ctx.logml_grad_batch(progs, tt, Y)
+    print("items", len(progs), "failed", int(np.count_nonzero(info)))
+else:
+    if config == "C5":
+        ctx.set_spec(default_spec(NGP_PREC_MIXED))
+    job = ctx.stage_predict(progs, tt, Y, w.t_new)
+    job.run()
+    out = job.fetch()
+    print("items", len(progs), "failed", int(np.count_nonzero(out["info"])))

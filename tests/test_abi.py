@@ -90,6 +90,21 @@ def test_weights_normalize_cols_equals_the_column_by_column_call(lib):
     assert np.array_equal(w[:, 0], w_ref) and ess[0] == ess_ref
 
 
+def test_rccl_entry_points_answer_cleanly_without_a_gpu(lib):
+    """ngp_comm_* open librccl at run time; without a usable device (this container) they answer
+    with a status instead of crashing or hanging."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    try:
+        uid = _lib.comm_unique_id()          # librccl may hand out an id without a device ...
+        assert len(uid) == 128
+    except _lib.NgpError as e:               # ... or refuse: then with the dedicated status
+        assert e.status == _lib.NGP_ERR_UNAVAILABLE
+    with pytest.raises(_lib.NgpError):       # a communicator needs a context, a context a GPU
+        _lib.Comm(_lib.Context(0), b"\0" * 128, 0, 1)
+
+
 def test_context_fails_loudly_without_a_gpu(lib):
     import torch
     if torch.cuda.is_available():

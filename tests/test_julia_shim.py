@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 JL = open(os.path.join(ROOT, "julia", "NGPAutoGP.jl"), encoding="utf-8").read()
 HDR = open(os.path.join(ROOT, "include", "ngp.h"), encoding="utf-8").read()
 
-HANDLES = ("ngp_ctx", "ngp_job", "ngp_factor")
+HANDLES = ("ngp_ctx", "ngp_job", "ngp_factor", "ngp_comm")
 STRUCTS = {"ngp_kernel": "NgpKernel", "ngp_spec": "NgpSpec", "ngp_profile": "NgpProfile"}
 SCALARS = {"int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "double": "Float64",
            "float": "Float32", "ngp_status": "Int32"}
@@ -27,8 +27,8 @@ def c_to_julia(ctype: str) -> str:
     t = re.sub(r"\bconst\b", "", ctype).strip()
     stars = t.count("*")
     base = t.replace("*", "").strip()
-    if base == "void" and stars == 0:
-        return "Cvoid"
+    if base == "void":
+        return "Cvoid" if stars == 0 else "Ptr{Cvoid}"
     if base == "char" and stars == 1:
         return "Cstring"
     if base in HANDLES:

@@ -167,3 +167,23 @@ def test_headline_c3_full_batch_against_the_oracle(eng):
     print(f"C3 full batch: {flat} of {len(picks)} sampled items under the flat 1e-8; "
           f"condition-limited (item, cond, err mean, err var): {listed}")
     assert flat >= len(picks) // 2
+
+
+def test_c_abi_collective_at_world_size_one(eng):
+    """ngp_weights_allgather_normalize over a librccl opened at run time: one
+    rank is the whole world, so the result must be ngp_weights_normalize_cols of the same matrix;
+    a ragged P_total / world split is exercised on CPU (tests/test_distributed_gloo.py) through the
+    same block partition."""
+    uid = _lib.comm_unique_id()
+    assert len(uid) == 128
+    comm = _lib.Comm(eng.ctx, uid, 0, 1)
+    rng = np.random.default_rng(4)
+    lw = -300.0 + 5.0 * rng.standard_normal((7, 4))
+    lw[3, 2] = -np.inf
+    w_loc, w_all, ess, ln = comm.allgather_normalize(lw, 7)
+    w_ref, ess_ref, ln_ref = _lib.weights_normalize_cols(lw)
+    assert np.array_equal(w_all, w_ref) and np.array_equal(w_loc, w_ref)
+    assert np.array_equal(ess, ess_ref) and np.array_equal(ln, ln_ref)
+    with pytest.raises(_lib.NgpError):
+        comm.allgather_normalize(lw, 0)
+    comm.close()
