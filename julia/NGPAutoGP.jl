@@ -227,6 +227,72 @@ function weights_normalize(logw::Vector{Float64})
     return w, ess[], ln[]
 end
 
+"Every COLUMN of a P x D log-weight matrix at once (include/ngp.h `ngp_weights_normalize_cols`): the D scenario clones."
+function weights_normalize_cols(logw::Matrix{Float64})          # P x D, column = scenario
+    P, D = size(logw)
+    lw = permutedims(logw)                                      # D x P column-major == [P x D] row-major
+    w = similar(lw); ess = Vector{Float64}(undef, D); ln = Vector{Float64}(undef, D)
+    check(ccall((:ngp_weights_normalize_cols, LIBNGP), Int32,
+                (Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                P, D, lw, w, ess, ln), "ngp_weights_normalize_cols")
+    return permutedims(w), ess, ln
+end
+
+"S independent mixtures of P components each, one device call (include/ngp.h `ngp_mixture_sample_indep`)."
+function mixture_sample_indep(c::Context, w::Matrix{Float64},        # P x S (column = mixture)
+                              mu::Array{Float64,3},                   # m x P x S
+                              sigma::Array{Float64,4},                # m x m x P x S
+                              draws::Integer, seeds::Vector{UInt64})
+    P, S, m = size(w, 1), size(w, 2), size(mu, 1)
+    out = Array{Float64}(undef, m, draws, S)
+    info = zeros(Int32, P, S)
+    check(ccall((:ngp_mixture_sample_indep, LIBNGP), Int32,
+                (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32,
+                 Ptr{UInt64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+                c.h, P, S, m, w, mu, sigma, draws, seeds, out, C_NULL, info),
+          "ngp_mixture_sample_indep")
+    raise_if_not_posdef(vec(info))
+    return out
+end
+
+"""
+The one collective of the path for a multi-GPU Julia host (one process per GPU): RCCL, opened by
+libngp at run time.  Rank 0 calls `comm_unique_id()` and hands the 128 bytes to the other ranks by
+whatever the host uses (Distributed.jl, MPI, a file); every rank then builds `Comm(ctx, id, rank, world)`.
+"""
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    check(ccall((:ngp_comm_unique_id, LIBNGP), Int32, (Ptr{Cvoid},), id), "ngp_comm_unique_id")
+    return id
+end
+mutable struct Comm
+    h::Ptr{Cvoid}
+    rank::Int
+    world::Int
+    ctx::Context
+    function Comm(c::Context, id::Vector{UInt8}, rank::Integer, world::Integer)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ngp_comm_create, LIBNGP), Int32,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ref{Ptr{Cvoid}}), c.h, id, rank, world, r),
+              "ngp_comm_create")
+        m = new(r[], rank, world, c)
+        finalizer(x -> ccall((:ngp_comm_destroy, LIBNGP), Cvoid, (Ptr{Cvoid},), x.h), m)
+        return m
+    end
+end
+"This rank's rows `logw_local` (P_local x D) -> (w_local, w_all, ess, log_norm) over ALL ranks' particles."
+function weights_allgather_normalize(cm::Comm, logw_local::Matrix{Float64}, P_total::Integer)
+    P_loc, D = size(logw_local)
+    lw = permutedims(logw_local)
+    w_loc = similar(lw); w_all = Matrix{Float64}(undef, D, P_total)
+    ess = Vector{Float64}(undef, D); ln = Vector{Float64}(undef, D)
+    check(ccall((:ngp_weights_allgather_normalize, LIBNGP), Int32,
+                (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                 Ptr{Float64}), cm.h, P_total, D, lw, w_loc, w_all, ess, ln),
+          "ngp_weights_allgather_normalize")
+    return permutedims(w_loc), permutedims(w_all), ess, ln
+end
+
 "info[b] > 0  =>  PosDefException(info[b]), as the reference surfaces it (src/make_and_fit_model.jl:6-8)."
 raise_if_not_posdef(info) = (k = findfirst(>(0), info); k === nothing || throw(PosDefException(info[k])))
 
@@ -360,8 +426,11 @@ mutable struct GPModel
     depth_cap::Int
     rng::AbstractRNG
     ctx::Context
+    n_particles_total::Int          # over all ranks (== length(particles) on one GPU)
 end
-num_particles(m::GPModel) = length(m.particles)
+GPModel(cfg, ds, y, parts, lw, lm, n_obs, perm, dss, dsi, ys, yi, cap, rng, ctx) =
+    GPModel(cfg, ds, y, parts, lw, lm, n_obs, perm, dss, dsi, ys, yi, cap, rng, ctx, length(parts))
+num_particles(m::GPModel) = m.n_particles_total
 
 _days(ds) = Float64[Dates.value(d) for d in ds]
 
@@ -405,9 +474,28 @@ end
 _advance(lw, new, old) = [isinf(n) && n < 0 ? -Inf : (v = w + (n - o); isnan(v) ? -Inf : v)
                           for (w, n, o) in zip(lw, new, old)]
 
-function _structure_move!(m::GPModel, t, y)
-    props = Program[]; idx = Int[]; trees = Node[]
-    for (k, p) in enumerate(m.particles)
+# ---- lockstep: the D scenario clones of forecast_with_nowcasts (src/forecasting.jl:131-159) advance
+#      together — every proposal / leapfrog / prediction is ONE call of P x D items with per-item y
+#      rows (ldy = n), instead of D tasks entering the library one after another.  Model j draws
+#      from its own `rng` in the order the single-model functions do, so the result is that of the
+#      per-scenario loop for the same seeds.  The single-model functions are the D = 1 case. ----
+"(t, Y): shared model times and the per-item observation rows (n x B, column = item)."
+function _group_obs(ms::Vector{GPModel})
+    t, y1 = _obs(ms[1])
+    ys = [y1]
+    for m in ms[2:end]
+        tj, yj = _obs(m)
+        (length(tj) == length(t) && tj == t) ||
+            throw(ArgumentError("models advanced in lockstep must share their observation dates"))
+        push!(ys, yj)
+    end
+    return t, ys
+end
+_item_y(ys, owner) = length(ys) == 1 ? ys[1] : reduce(hcat, (ys[j] for j in owner))
+
+function _structure_move!(ms::Vector{GPModel}, t, ys)
+    props = Program[]; idx = Tuple{Int, Int}[]
+    for (j, m) in enumerate(ms), (k, p) in enumerate(m.particles)
         tree = from_program(p)
         nodes = Tuple{Node, Int, Union{Nothing, Node}, Symbol}[]
         walk(nd, depth, parent, side) = (push!(nodes, (nd, depth, parent, side));
@@ -418,103 +506,141 @@ function _structure_move!(m::GPModel, t, y)
         new = parent === nothing ? sub : (setfield!(parent, side, sub); tree)
         prog = to_program(new, p.noise)
         kernel_check(prog) || continue
-        push!(props, prog); push!(idx, k); push!(trees, new)
+        push!(props, prog); push!(idx, (j, k))
     end
     isempty(props) && return 0
-    lm, info = logml_batch(m.ctx, props, t, y)
+    lm, info = logml_batch(ms[1].ctx, props, t, _item_y(ys, [j for (j, _) in idx]))
     acc = 0
-    for (j, k) in enumerate(idx)
-        (info[j] != 0 || !isfinite(lm[j])) && continue
-        log_a = (lm[j] - m.logml[k]) + log(length(m.particles[k].ops) / length(props[j].ops))
+    for (i, (j, k)) in enumerate(idx)
+        (info[i] != 0 || !isfinite(lm[i])) && continue
+        m = ms[j]
+        log_a = (lm[i] - m.logml[k]) + log(length(m.particles[k].ops) / length(props[i].ops))
         if log(rand(m.rng)) < log_a
-            m.particles[k] = props[j]; m.logml[k] = lm[j]; acc += 1
+            m.particles[k] = props[i]; m.logml[k] = lm[i]; acc += 1
         end
     end
     return acc
 end
+_structure_move!(m::GPModel, t, y) = _structure_move!([m], t, [y])
 
-"One HMC transition per particle on the N(0,1) latents of (parameters, noise)."
-function _hmc_move!(m::GPModel, t, y, n_leapfrog::Int, eps::Float64)
-    prior = m.config.prior
-    fixed_noise = m.config.noise !== nothing
-    P = length(m.particles)
-    kinds = [vcat(param_kinds(p), [:wildcard]) for p in m.particles]
+"One HMC transition per particle of every model on the N(0,1) latents of (parameters, noise)."
+function _hmc_move!(ms::Vector{GPModel}, t, ys, n_leapfrog::Int, eps::Float64)
+    prior = ms[1].config.prior
+    fixed_noise = ms[1].config.noise !== nothing
+    items = [(j, k) for (j, m) in enumerate(ms) for k in 1:length(m.particles)]
+    B = length(items)
+    parts = [ms[j].particles[k] for (j, k) in items]
+    Y = _item_y(ys, [j for (j, _) in items])
+    kinds = [vcat(param_kinds(p), [:wildcard]) for p in parts]
     z0 = [[untransform(th, k, prior) for (th, k) in zip(vcat(p.params, p.noise), kd)]
-          for (p, kd) in zip(m.particles, kinds)]
+          for (p, kd) in zip(parts, kinds)]
     function potential(z)
         progs = Program[]; dths = Vector{Float64}[]
-        for (p, kd, zk) in zip(m.particles, kinds, z)
+        for (p, kd, zk) in zip(parts, kinds, z)
             td = [transform(clamp(isnan(v) ? 0.0 : v, -50.0, 50.0), k, prior) for (v, k) in zip(zk, kd)]
             th = [clamp(a[1], -1.0e6, 1.0e6) for a in td]
             push!(dths, [a[2] for a in td])
             push!(progs, Program(p.ops, th[1:end-1], max(th[end], 1.0e-12)))
         end
-        lm, grads, info = logml_grad_batch(m.ctx, progs, t, y)
+        lm, grads, info = logml_grad_batch(ms[1].ctx, progs, t, Y)    # ONE call of P x D items
         U = similar(lm); dU = Vector{Float64}[]
-        for k in 1:P
-            ok = info[k] == 0 && isfinite(lm[k]) && all(isfinite, grads[k])
-            U[k] = ok ? -lm[k] + 0.5 * sum(abs2, z[k]) : Inf
-            g = ok ? (-grads[k] .* dths[k] .+ z[k]) : zeros(length(z[k]))
+        for i in 1:B
+            ok = info[i] == 0 && isfinite(lm[i]) && all(isfinite, grads[i])
+            U[i] = ok ? -lm[i] + 0.5 * sum(abs2, z[i]) : Inf
+            g = ok ? (-grads[i] .* dths[i] .+ z[i]) : zeros(length(z[i]))
             fixed_noise && (g[end] = 0.0)
             push!(dU, g)
         end
         return U, dU, lm, progs
     end
     U0, dU, _, _ = potential(z0)
-    mom = [randn(m.rng, length(zk)) for zk in z0]
+    mom = [randn(ms[j].rng, length(z0[i])) for (i, (j, _)) in enumerate(items)]
     fixed_noise && foreach(p -> (p[end] = 0.0), mom)
-    H0 = [U0[k] + 0.5 * sum(abs2, mom[k]) for k in 1:P]
+    H0 = [U0[i] + 0.5 * sum(abs2, mom[i]) for i in 1:B]
     z = deepcopy(z0)
-    pm = [mom[k] .- 0.5 * eps .* dU[k] for k in 1:P]
-    U1 = U0; lm1 = zeros(P); progs1 = m.particles
+    pm = [mom[i] .- 0.5 * eps .* dU[i] for i in 1:B]
+    U1 = U0; lm1 = zeros(B); progs1 = parts
     for step in 1:n_leapfrog
-        z = [z[k] .+ eps .* pm[k] for k in 1:P]
+        z = [z[i] .+ eps .* pm[i] for i in 1:B]
         U1, dU, lm1, progs1 = potential(z)
         h = step < n_leapfrog ? eps : 0.5 * eps
-        pm = [pm[k] .- h .* dU[k] for k in 1:P]
+        pm = [pm[i] .- h .* dU[i] for i in 1:B]
     end
     acc = 0
-    for k in 1:P
-        H1 = U1[k] + 0.5 * sum(abs2, pm[k])
-        u = rand(m.rng)
-        if isfinite(H1) && log(u) < H0[k] - H1
-            m.particles[k] = progs1[k]; m.logml[k] = lm1[k]; acc += 1
+    for (i, (j, k)) in enumerate(items)
+        H1 = U1[i] + 0.5 * sum(abs2, pm[i])
+        u = rand(ms[j].rng)
+        if isfinite(H1) && log(u) < H0[i] - H1
+            ms[j].particles[k] = progs1[i]; ms[j].logml[k] = lm1[i]; acc += 1
         end
     end
     return acc
 end
+_hmc_move!(m::GPModel, t, y, n_leapfrog::Int, eps::Float64) = _hmc_move!([m], t, [y], n_leapfrog, eps)
 
 const DEFAULT_HMC = (n_leapfrog = 10, eps = 0.02)
 
 "AutoGP.mcmc_parameters!(model, n_hmc) — src/forecasting.jl:65, 148"
 function mcmc_parameters!(m::GPModel, n_hmc::Int; hmc_config = DEFAULT_HMC)
-    t, y = _obs(m)
-    for _ in 1:n_hmc
-        _hmc_move!(m, t, y, hmc_config.n_leapfrog, hmc_config.eps)
-    end
+    mcmc_parameters_lockstep!([m], n_hmc; hmc_config)
     return m
+end
+function mcmc_parameters_lockstep!(ms::Vector{GPModel}, n_hmc::Int; hmc_config = DEFAULT_HMC)
+    t, ys = _group_obs(ms)
+    for _ in 1:n_hmc
+        _hmc_move!(ms, t, ys, hmc_config.n_leapfrog, hmc_config.eps)
+    end
+    return ms
 end
 
 "AutoGP.mcmc_structure!(model, n_mcmc, n_hmc) — src/forecasting.jl:146"
 function mcmc_structure!(m::GPModel, n_mcmc::Int, n_hmc::Int; hmc_config = DEFAULT_HMC)
-    t, y = _obs(m)
+    mcmc_structure_lockstep!([m], n_mcmc, n_hmc; hmc_config)
+    return m
+end
+function mcmc_structure_lockstep!(ms::Vector{GPModel}, n_mcmc::Int, n_hmc::Int;
+                                  hmc_config = DEFAULT_HMC)
+    t, ys = _group_obs(ms)
     for _ in 1:n_mcmc
-        _structure_move!(m, t, y)
+        _structure_move!(ms, t, ys)
         for _ in 1:n_hmc
-            _hmc_move!(m, t, y, hmc_config.n_leapfrog, hmc_config.eps)
+            _hmc_move!(ms, t, ys, hmc_config.n_leapfrog, hmc_config.eps)
         end
     end
-    return m
+    return ms
 end
 
 "AutoGP.maybe_resample!(model, ess) — src/forecasting.jl:138-141 (absolute ESS threshold)"
 function maybe_resample!(m::GPModel, ess_threshold::Real)
-    w, ess, _ = weights_normalize(m.log_weights)
-    ess < ess_threshold || return false
-    cw = cumsum(w)
-    anc = [min(searchsortedfirst(cw, rand(m.rng)), length(w)) for _ in 1:length(w)]
-    m.particles = m.particles[anc]; m.logml = m.logml[anc]; fill!(m.log_weights, 0.0)
-    return true
+    return maybe_resample_lockstep!([m], ess_threshold)[1]
+end
+"""
+D models at once: ONE normalisation call for all weight vectors (`ngp_weights_normalize_cols`;
+`comm`: one RCCL all-gather over the ranks' particle shards, `ngp_weights_allgather_normalize`).
+In a multi-GPU host every rank draws the same ancestors (same `rng` state on every rank) and
+rebuilds its shard from the descriptors the host exchanges — no matrix ever moves.
+"""
+function maybe_resample_lockstep!(ms::Vector{GPModel}, ess_threshold::Real;
+                                  comm::Union{Nothing, Comm} = nothing)
+    logw = reduce(hcat, (m.log_weights for m in ms))               # P_local x D
+    if comm === nothing
+        w, ess, _ = weights_normalize_cols(logw)
+    else
+        P_total = ms[1].n_particles_total
+        _, w, ess, _ = weights_allgather_normalize(comm, logw, P_total)
+        comm.world == 1 || error("multi-rank resampling: exchange the particle descriptors " *
+                                 "(ops, params, noise, logml) between ranks in the host, then rebuild " *
+                                 "this rank's shard from ancestors[shard] as below")
+    end
+    done = falses(length(ms))
+    for (j, m) in enumerate(ms)
+        ess[j] < ess_threshold || continue
+        cw = cumsum(w[:, j])
+        anc = [min(searchsortedfirst(cw, rand(m.rng)), length(cw)) for _ in 1:length(cw)]
+        m.particles = m.particles[anc]; m.logml = m.logml[anc]; fill!(m.log_weights, 0.0)
+        done[j] = true
+    end
+    return done
 end
 
 """
@@ -555,6 +681,33 @@ function add_data!(m::GPModel, ds::AbstractVector{<:Dates.TimeType}, y::Abstract
     return m
 end
 
+"""
+`add_data!` on D clones of `base` at once: the appended covariance rows do not depend on the
+scenario, so all D weight updates are ONE query of the base model's factor (P factorisations at
+most — `ngp_nowcast_batch`, or none with a resident `Factor`), not P x D.
+"""
+function add_data_lockstep!(ms::Vector{GPModel}, ds::AbstractVector{<:Dates.TimeType},
+                            ys::Vector{<:AbstractVector{<:Real}}, base::GPModel;
+                            factor::Union{Nothing, Factor} = nothing)
+    length(ys) == length(ms) && all(length(y) == length(ds) for y in ys) ||
+        throw(ArgumentError("one vector of length(ds) observations per model"))
+    t, y = _obs(base)
+    t_add = base.ds_slope .* _days(ds) .+ base.ds_intercept
+    y_add = reduce(hcat, (base.y_slope .* Float64.(v) .+ base.y_intercept for v in ys))   # d x D
+    o = factor === nothing ? nowcast_batch(base.ctx, base.particles, t, y, t_add, y_add, Float64[]) :
+                             nowcast(factor, t_add, y_add, Float64[])
+    for (j, m) in enumerate(ms)
+        n_old = length(m.y)
+        append!(m.ds, ds); append!(m.y, ys[j]); append!(m.perm, n_old+1:n_old+length(ds))
+        lm = [(o.info[k] != 0 || !isfinite(o.logml_full[j, k])) ? -Inf : o.logml_full[j, k]
+              for k in 1:length(m.particles)]
+        m.log_weights = _advance(m.log_weights, lm, m.logml)
+        m.logml = lm
+        m.n_obs = length(m.y)
+    end
+    return ms
+end
+
 struct Mixture
     means::Matrix{Float64}      # m x P
     covs::Array{Float64, 3}     # m x m x P
@@ -571,14 +724,83 @@ end
 Base.rand(d::Mixture, k::Integer) = rand(Random.default_rng(), d, k)     # src/forecasting.jl:47
 Base.rand(d::Mixture) = vec(rand(d, 1))                                  # src/forecasting.jl:67
 
+const NGP_MAX_AUX = 192      # include/ngp.h: appended + forecast rows one call carries
+"""
+Forecast dates one library call carries beside n observations and d appended points
+(include/ngp.h: (n mod 64) + d + m + 1 <= NGP_MAX_AUX).  The Python mirror serves longer horizons
+by querying blocks of dates pairwise (nowcastautogp_amd/autogp.py `horizon_blocks`,
+`predict_in_blocks`); this shim states the limit instead.
+"""
+horizon_room(n_obs::Int, d::Int = 0) = NGP_MAX_AUX - n_obs % 64 - d - 1
+function _check_horizon(n_obs::Int, m::Int)
+    m <= horizon_room(n_obs) || throw(ArgumentError(
+        "predict_mvn: $m forecast dates, but one call carries at most $(horizon_room(n_obs)) beside " *
+        "$n_obs observations (NGP_MAX_AUX = $NGP_MAX_AUX); query the dates in blocks"))
+end
+
 "AutoGP.predict_mvn(model, dates) — src/forecasting.jl:46, 66"
 function predict_mvn(m::GPModel, dates::AbstractVector{<:Dates.TimeType})
-    t, y = _obs(m)
-    t_new = m.ds_slope .* _days(dates) .+ m.ds_intercept
-    mu, sigma, _, info = predict_batch(m.ctx, m.particles, t, y, t_new)
+    return predict_mvn_lockstep([m], dates)[1]
+end
+"D models on the same dates: ONE `ngp_predict_batch` call of P x D items."
+function predict_mvn_lockstep(ms::Vector{GPModel}, dates::AbstractVector{<:Dates.TimeType})
+    t, ys = _group_obs(ms)
+    _check_horizon(length(t), length(dates))
+    t_new = ms[1].ds_slope .* _days(dates) .+ ms[1].ds_intercept
+    progs = reduce(vcat, (m.particles for m in ms))
+    owner = [j for (j, m) in enumerate(ms) for _ in m.particles]
+    mu, sigma, _, info = predict_batch(ms[1].ctx, progs, t, _item_y(ys, owner), t_new)
     raise_if_not_posdef(info)
-    w, _, _ = weights_normalize(m.log_weights)
-    return Mixture((mu .- m.y_intercept) ./ m.y_slope, sigma ./ m.y_slope^2, w)
+    w, _, _ = weights_normalize_cols(reduce(hcat, (m.log_weights for m in ms)))
+    out = Mixture[]
+    off = 0
+    for (j, m) in enumerate(ms)
+        r = off+1:off+length(m.particles)
+        push!(out, Mixture((mu[:, r] .- m.y_intercept) ./ m.y_slope, sigma[:, :, r] ./ m.y_slope^2,
+                           w[:, j]))
+        off += length(m.particles)
+    end
+    return out
+end
+
+"""
+What `forecast_with_nowcasts` (src/forecasting.jl:117-167) does with its scenarios, as ONE ensemble
+instead of one `Threads.@spawn` task per scenario: clone, `add_data!`, `maybe_resample!`, the
+requested refinement, then the forecast draws — every step one library call of P x D items.  A
+maintainer replaces the task fan-out (src/forecasting.jl:131-165) by a call of this function; the
+result is the `hcat` of the per-scenario forecasts (m x (D * draws)), before `inv_transformation`.
+"""
+function forecast_with_nowcasts_lockstep(base::GPModel, nowcast_ds::AbstractVector{<:Dates.TimeType},
+                                         nowcast_ys::Vector{<:AbstractVector{<:Real}},
+                                         dates::AbstractVector{<:Dates.TimeType}, draws::Int;
+                                         n_mcmc::Int = 0, n_hmc::Int = 0, ess_threshold::Real = 0.0,
+                                         forecast_n_hmc::Union{Nothing, Int} = nothing,
+                                         hmc_config = DEFAULT_HMC)
+    snapshot = Dict(base)                                                   # src/forecasting.jl:128
+    ms = [GPModel(deepcopy(snapshot); ctx = base.ctx, rng = Random.Xoshiro(rand(base.rng, UInt64)))
+          for _ in nowcast_ys]                                              # :133, own stream each
+    add_data_lockstep!(ms, nowcast_ds, nowcast_ys, base)                    # :135
+    maybe_resample_lockstep!(ms, ess_threshold * num_particles(base))       # :138-141
+    if n_mcmc > 0 && n_hmc > 0
+        mcmc_structure_lockstep!(ms, n_mcmc, n_hmc; hmc_config)             # :146
+    elseif n_hmc > 0
+        mcmc_parameters_lockstep!(ms, n_hmc; hmc_config)                    # :148
+    end
+    m = length(dates)
+    out = [Matrix{Float64}(undef, m, draws) for _ in ms]
+    if forecast_n_hmc === nothing                                           # :39-52
+        for (o, mix, mdl) in zip(out, predict_mvn_lockstep(ms, dates), ms)
+            o .= rand(mdl.rng, mix, draws)
+        end
+    else                                                                    # :54-75
+        for i in 1:draws
+            mcmc_parameters_lockstep!(ms, forecast_n_hmc; hmc_config)
+            for (o, mix, mdl) in zip(out, predict_mvn_lockstep(ms, dates), ms)
+                o[:, i] = vec(rand(mdl.rng, mix, 1))
+            end
+        end
+    end
+    return reduce(hcat, out)
 end
 
 # ---- Dict(model) / GPModel(::Dict): the version-1 wire format of nowcastautogp_amd/wire.py
@@ -623,6 +845,12 @@ function GPModel(d::AbstractDict; ctx::Context = default_context(),
                    max_depth = c["max_depth"], changepoints = c["changepoints"],
                    noise = c["noise"] === nothing ? nothing : Float64(c["noise"]), prior = prior)
     d["data"]["ds_kind"] == "date" || throw(ArgumentError("this reader needs date-valued ds"))
+    # the cached per-particle logml belongs to the formula variants / jitter it was computed under
+    # (nowcastautogp_amd/wire.py refuses the same mismatch)
+    sp, ws = get_spec(ctx), d["spec"]
+    (ws["se_form"] == sp.se_form && ws["periodic_form"] == sp.periodic_form &&
+     ws["cp_form"] == sp.cp_form && ws["jitter"] == sp.jitter) ||
+        throw(ArgumentError("ngp-model dict was written under another spec than this context runs"))
     parts = [Program(Int32.(p["ops"]), Float64.(p["params"]), Float64(p["noise"]))
              for p in d["particles"]]
     tr = d["transforms"]

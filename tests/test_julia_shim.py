@@ -173,6 +173,30 @@ def test_the_autogp_surface_of_the_reference_is_defined():
     assert re.search(r"mutable struct GPModel\n\s+config::GPConfig", JL)
 
 
+def test_the_lockstep_ensemble_and_its_limits_are_there():
+    """VERDICT r2 item 1 / ADVICE r2: the shim carries the same lockstep loop as the Python mirror
+    (one library call of P x D items per step of the D scenario clones), states the horizon a call
+    carries instead of failing inside the library, and refuses a dict written under another spec."""
+    for name in ("add_data_lockstep!", "maybe_resample_lockstep!", "mcmc_parameters_lockstep!",
+                 "mcmc_structure_lockstep!", "predict_mvn_lockstep", "forecast_with_nowcasts_lockstep"):
+        assert re.search(r"function " + re.escape(name) + r"\(", JL), name
+    # the single-model surface is the D = 1 case of the lockstep functions
+    for single, multi in (("mcmc_parameters!", "mcmc_parameters_lockstep!"),
+                          ("mcmc_structure!", "mcmc_structure_lockstep!"),
+                          ("maybe_resample!", "maybe_resample_lockstep!"),
+                          ("predict_mvn", "predict_mvn_lockstep")):
+        body = re.search(r"function " + re.escape(single) + r"\(m::GPModel.*?\nend\n", JL, re.S).group(0)
+        assert multi + "([m]" in body, single
+    # every leapfrog is ONE gradient call over all items, with per-item y rows
+    hmc = re.search(r"function _hmc_move!\(ms::Vector\{GPModel\}.*?\nend\n", JL, re.S).group(0)
+    assert hmc.count("logml_grad_batch(") == 1 and "_item_y(ys" in hmc
+    assert "NGP_MAX_AUX = 192" in JL and "_check_horizon(length(t), length(dates))" in JL
+    hdr_aux = int(re.search(r"#define NGP_MAX_AUX\s+(\d+)", HDR).group(1))
+    assert hdr_aux == 192
+    reader = re.search(r"function GPModel\(d::AbstractDict.*?\nend\n", JL, re.S).group(0)
+    assert 'd["spec"]' in reader and "get_spec(ctx)" in reader
+
+
 def test_dict_uses_the_version_1_wire_keys():
     with open(os.path.join(ROOT, "tests", "golden", "model_dict_v1.json")) as f:
         golden = json.load(f)["model"]
