@@ -177,10 +177,9 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
     if n_mcmc == 0 and n_hmc == 0 and forecast_n_hmc is None and same_dates and lockstep:
         return _forecast_with_nowcasts_batched(base_model, nowcasts, dates, draws,
                                                inv_transformation, ess_threshold)
-    base = base_model.to_dict()
-
     def clone():
-        m = GPModel.from_dict(copy.deepcopy(base), engine=base_model.engine)
+        # GPModel(deepcopy(Dict(base_model))) of the reference (src/forecasting.jl:128,133)
+        m = base_model.clone()
         # every scenario is its own task with its own randomness in the reference
         # (src/forecasting.jl:131-133); a clone that kept the snapshot's stream would repeat the
         # first scenario's draws.  Splitting also advances the base model's streams, so a second

@@ -311,3 +311,19 @@ def test_lockstep_models_must_share_their_dates(eng):
     scen = [nc.TData(mc.days(20, 22), [101.0, 102.0], transformation=ident),
             nc.TData(mc.days(20, 21), [101.5], transformation=ident)]
     assert nc.forecast_with_nowcasts(base, scen, mc.days(22, 24), 3, n_hmc=1).shape == (2, 6)
+
+
+def test_clone_is_the_snapshot_round_trip(eng):
+    """forecast_with_nowcasts clones the base model per scenario (reference
+    src/forecasting.jl:128,133: GPModel(deepcopy(Dict(model)))); the direct clone must be that
+    round trip, state for state, and independent of its source afterwards."""
+    import copy
+    model = mc.fitted(eng, seed=34, n_particles=3)
+    a = model.clone()
+    b = nc.GPModel.from_dict(copy.deepcopy(model.to_dict()), engine=eng)
+    assert a.to_dict() == b.to_dict() == model.to_dict()
+    before = model.to_dict()
+    autogp.add_data(a, mc.days(20, 22), [101.0, 99.0])
+    autogp.mcmc_structure(a, 2, 1)
+    autogp.maybe_resample(a, 10.0)
+    assert model.to_dict() == before                       # the source is untouched
