@@ -223,6 +223,8 @@ ngp_status ngp_weights_normalize_cols(int32_t P, int32_t D, const double *logw,
  *        w_local [P_local x D] (may be NULL), w_all [P_total x D] (may be NULL: what resampling
  *        needs), ess [D], log_norm [D] (may be NULL).  Identical on every rank.                */
 typedef struct ngp_comm ngp_comm;
+/* the block partition itself (host-only arithmetic): rank's first global particle and its count */
+ngp_status ngp_shard(int32_t P_total, int32_t world, int32_t rank, int32_t *first, int32_t *rows);
 ngp_status ngp_comm_unique_id(void *id128);
 ngp_status ngp_comm_create(ngp_ctx *ctx, const void *id128, int32_t rank, int32_t world,
                            ngp_comm **out);

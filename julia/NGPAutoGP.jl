@@ -260,6 +260,13 @@ The one collective of the path for a multi-GPU Julia host (one process per GPU):
 libngp at run time.  Rank 0 calls `comm_unique_id()` and hands the 128 bytes to the other ranks by
 whatever the host uses (Distributed.jl, MPI, a file); every rank then builds `Comm(ctx, id, rank, world)`.
 """
+"(first, rows) of `rank` in the block partition of P_total particles over `world` ranks (0-based)."
+function shard(P_total::Integer, world::Integer, rank::Integer)
+    a = Ref{Int32}(0); b = Ref{Int32}(0)
+    check(ccall((:ngp_shard, LIBNGP), Int32, (Int32, Int32, Int32, Ref{Int32}, Ref{Int32}),
+                P_total, world, rank, a, b), "ngp_shard")
+    return Int(a[]), Int(b[])
+end
 function comm_unique_id()
     id = Vector{UInt8}(undef, 128)
     check(ccall((:ngp_comm_unique_id, LIBNGP), Int32, (Ptr{Cvoid},), id), "ngp_comm_unique_id")

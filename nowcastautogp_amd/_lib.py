@@ -27,7 +27,7 @@ SYMBOLS = (
     "ngp_ctx_create", "ngp_ctx_destroy", "ngp_set_spec", "ngp_get_spec", "ngp_default_spec",
     "ngp_strerror", "ngp_version", "ngp_kernel_check", "ngp_cov_batch", "ngp_logml_batch",
     "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
-    "ngp_weights_normalize_cols", "ngp_mixture_sample_indep", "ngp_comm_unique_id", "ngp_comm_create",
+    "ngp_weights_normalize_cols", "ngp_mixture_sample_indep", "ngp_shard", "ngp_comm_unique_id", "ngp_comm_create",
     "ngp_comm_destroy", "ngp_weights_allgather_normalize",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
     "ngp_job_mixed_stats", "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
@@ -87,6 +87,7 @@ def load():
         "ngp_weights_normalize_cols": (i32, [i32, i32, f64p, f64p, f64p, f64p]),
         "ngp_mixture_sample_indep": (i32, [vp, i32, i32, i32, f64p, f64p, f64p, i32,
                                            C.POINTER(C.c_uint64), f64p, i32p, i32p]),
+        "ngp_shard": (i32, [i32, i32, i32, i32p, i32p]),
         "ngp_comm_unique_id": (i32, [vp]),
         "ngp_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
         "ngp_comm_destroy": (None, [vp]),
@@ -163,6 +164,13 @@ def weights_normalize_cols(logw):
 
 
 NGP_ERR_UNAVAILABLE = -6
+
+
+def shard(P_total: int, world: int, rank: int):
+    """(first, rows) of ``rank`` in the block partition the library's collective uses (``ngp_shard``)."""
+    a, b = C.c_int32(), C.c_int32()
+    _chk(load().ngp_shard(int(P_total), int(world), int(rank), C.byref(a), C.byref(b)), "ngp_shard")
+    return int(a.value), int(b.value)
 
 
 def comm_unique_id() -> bytes:

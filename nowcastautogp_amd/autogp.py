@@ -314,12 +314,14 @@ class GPModel:
         from . import wire
         wire.model_from_wire(self, d)
 
-    def clone(self) -> "GPModel":
+    def clone(self, root: Optional[int] = None) -> "GPModel":
         """What ``GPModel(deepcopy(Dict(model)))`` gives (reference src/forecasting.jl:128,133),
         without the round trip through the wire dict: with a few thousand observations that trip
         is 30 ms per clone, and forecast_with_nowcasts makes one clone per scenario.  Kernel trees
         are shared between the clones — no move mutates a tree in place (a proposal works on its
-        own copy, an accepted move installs a new tree) — everything else is copied."""
+        own copy, an accepted move installs a new tree) — everything else is copied.  ``root``:
+        give the clone fresh random streams right away (``reseed``) instead of copies of this
+        model's — what forecast_with_nowcasts wants for its scenarios."""
         m = GPModel.__new__(GPModel)
         m.engine = self.engine
         m.config = copy.deepcopy(self.config)
@@ -329,8 +331,6 @@ class GPModel:
         m.y_transform = LinearTransform(self.y_transform.slope, self.y_transform.intercept)
         m.depth_cap = self.depth_cap
         m._root, m._gen = self._root, self._gen
-        m.rng_shared = copy.deepcopy(self.rng_shared)
-        m.prng = [copy.deepcopy(r) for r in self.prng]
         m.n_particles_total = self.n_particles_total
         m.particles = [Particle(p.tree, p.noise) for p in self.particles]
         m.log_weights = self.log_weights.copy()
@@ -339,6 +339,11 @@ class GPModel:
         m._logml = self._logml.copy()
         if hasattr(self, "wire_spec"):
             m.wire_spec = dict(self.wire_spec)
+        if root is None:
+            m.rng_shared = copy.deepcopy(self.rng_shared)
+            m.prng = [copy.deepcopy(r) for r in self.prng]
+        else:
+            m.reseed(root)
         return m
 
     def reseed(self, root: int) -> None:
@@ -458,6 +463,19 @@ def _item_y(ys, owner):
     return np.stack(ys)[np.asarray(owner, dtype=np.int64)]
 
 
+_KIND_CODE_CACHE = {}
+
+
+def _kind_codes(ops) -> tuple:
+    """KIND_CODES of a program's parameters followed by the noise, cached by opcode sequence."""
+    key = ops.tobytes()
+    got = _KIND_CODE_CACHE.get(key)
+    if got is None:
+        got = tuple(gp.KIND_CODES[k] for k in gp.param_kinds(ops) + [gp.NOISE_KIND])
+        _KIND_CODE_CACHE[key] = got
+    return got
+
+
 def _all_items_y(models, ys):
     """``_item_y`` for the call that carries every particle of every model (210 MB at 64 x 200
     items of 2049 points: built once per group of moves, not once per move)."""
@@ -515,19 +533,21 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
         return 0
     part = [models[j].particles[k] for j, k in items]
     prng = [models[j].prng[k] for j, k in items]
-    ops, z0 = [], []
-    codes_l = []
+    ops, theta0, codes_l, sizes = [], [], [], []
     for p in part:
         o, params = gp.to_program(p.tree)
-        kd = gp.param_kinds(o) + [gp.NOISE_KIND]
+        kc = _kind_codes(o)
         ops.append(o)
-        z0.append(gp.untransform(np.concatenate([params, [p.noise]]), kd, prior))
-        codes_l.extend(gp.KIND_CODES[k_] for k_ in kd)
-    sizes = np.array([z.size for z in z0])
+        theta0.append(params)
+        theta0.append((p.noise,))
+        codes_l.extend(kc)
+        sizes.append(len(kc))
+    sizes = np.array(sizes)
     off = np.concatenate([[0], np.cumsum(sizes)])
     sl = [slice(int(off[i]), int(off[i + 1])) for i in range(B)]
     seg = np.repeat(np.arange(B), sizes)                     # item of every latent
     codes = np.array(codes_l)
+    z0 = gp.untransform_flat(np.concatenate(theta0), codes, prior)
     last = off[1:] - 1                                       # the noise latent of every item
     positive = (codes == gp.KIND_CODES["wildcard"]) | (codes == gp.KIND_CODES["period"])
     is_gamma, is_unit = codes == gp.KIND_CODES["gamma"], codes == gp.KIND_CODES["unit"]
@@ -568,7 +588,6 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
             dU[last] = 0.0
         return U, dU, lm
 
-    z0 = np.concatenate(z0)
     U0, dU, _ = potential(z0)
     mom = np.concatenate([prng[i].standard_normal(int(sizes[i])) for i in range(B)])
     if fixed_noise:

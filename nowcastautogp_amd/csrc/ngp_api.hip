@@ -1560,7 +1560,9 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     int Bc = (int)std::min<size_t>(std::min<size_t>((size_t)B, MAX_CHUNK_ITEMS),
                                    std::max<size_t>(1, c->mem_cap / item_bytes));
     void *d_prog, *d_t, *d_y, *d_q = nullptr, *d_logdet, *d_info, *d_L, *d_dinv, *d_tab = nullptr,
-         *d_sig = nullptr, *d_dtab = nullptr, *d_kinv, *d_alpha, *d_quad, *d_part, *d_grad, *d_logml;
+         *d_sig = nullptr, *d_dtab = nullptr, *d_kinv, *d_alpha, *d_quad, *d_part, *d_grad, *d_logml,
+         *d_items;
+    std::vector<int32_t> h_items((size_t)B);   // alive until the stream is synchronised below
     ngp_status st;
     // the chunk is halved when the device cannot hold it after all (other handles, rounding)
     for (;; Bc = (Bc + 1) / 2) {
@@ -1580,7 +1582,8 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
               (st = dalloc(&d_part,
                            8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc), 4096) *
                                GP)) ||
-              (st = dalloc(&d_grad, 8 * (size_t)B * GP)) || (st = dalloc(&d_logml, 8 * (size_t)B))))
+              (st = dalloc(&d_grad, 8 * (size_t)B * GP)) || (st = dalloc(&d_logml, 8 * (size_t)B)) ||
+              (st = dalloc(&d_items, 4 * (size_t)B))))
             break;
         freeall();
         owned.clear();
@@ -1622,11 +1625,29 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
             launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
                              (double *)d_quad, bc, s);
         });
+        // the chunk's items sorted by tree size: every size class runs on the contraction kernel
+        // sized for it
+        int32_t counts[GRAD_BUCKETS] = {0, 0, 0, 0};
+        {
+            for (int i = 0; i < bc; ++i) ++counts[grad_bucket(kernels[b0 + i].n_ops)];
+            int32_t pos[GRAD_BUCKETS], acc = 0;
+            for (int k = 0; k < GRAD_BUCKETS; ++k) { pos[k] = acc; acc += counts[k]; }
+            for (int i = 0; i < bc; ++i)
+                h_items[(size_t)b0 + (size_t)pos[grad_bucket(kernels[b0 + i].n_ops)]++] = i;
+            const hipError_t ce = hipMemcpyAsync((int32_t *)d_items + b0, h_items.data() + b0,
+                                                 4 * (size_t)bc, hipMemcpyHostToDevice, s);
+            if (ce != hipSuccess) {
+                (void)hipStreamSynchronize(s);
+                tm.resolve(c->prof);
+                freeall();
+                return (ngp_status)ce;
+            }
+        }
         tm.run(11, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
             launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
                                  (const double *)d_quad, (double *)d_part,
                                  (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc,
-                                 sp, s);
+                                 sp, s, g.lattice ? (const int32_t *)d_items + b0 : nullptr, counts);
         });
     }
     std::vector<double> h_grad((size_t)B * GP), h_lm((size_t)B);
@@ -1846,17 +1867,25 @@ extern "C" void ngp_comm_destroy(ngp_comm *m) {
     delete m;
 }
 
+extern "C" ngp_status ngp_shard(int32_t P_total, int32_t world, int32_t rank, int32_t *first,
+                                int32_t *rows) {
+    if (P_total < 0 || world <= 0 || rank < 0 || rank >= world) return NGP_ERR_ARG;
+    const int base = P_total / world, rem = P_total % world;
+    if (first) *first = rank * base + std::min(rank, rem);
+    if (rows) *rows = base + (rank < rem ? 1 : 0);
+    return NGP_OK;
+}
+
 extern "C" ngp_status ngp_weights_allgather_normalize(ngp_comm *m, int32_t P_total, int32_t D,
                                                       const double *logw_local, double *w_local,
                                                       double *w_all, double *ess,
                                                       double *log_norm) {
     if (!m || !logw_local || P_total <= 0 || D <= 0 || P_total < m->world) return NGP_ERR_ARG;
-    // block partition of the particles over the ranks, remainder to the low ranks (the partition
-    // nowcastautogp_amd.distributed.shard and the Julia shim use)
-    const int base = P_total / m->world, rem = P_total % m->world;
-    auto rows_of = [&](int r) { return base + (r < rem ? 1 : 0); };
-    auto first_of = [&](int r) { return r * base + std::min(r, rem); };
-    const int mine = rows_of(m->rank), pmax = base + (rem ? 1 : 0);
+    // block partition of the particles over the ranks, remainder to the low ranks (ngp_shard: the
+    // partition nowcastautogp_amd.distributed.shard and the Julia shim use)
+    auto rows_of = [&](int r) { int32_t v = 0; (void)ngp_shard(P_total, m->world, r, nullptr, &v); return (int)v; };
+    auto first_of = [&](int r) { int32_t v = 0; (void)ngp_shard(P_total, m->world, r, &v, nullptr); return (int)v; };
+    const int mine = rows_of(m->rank), pmax = rows_of(0);
     ngp_ctx *c = m->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));

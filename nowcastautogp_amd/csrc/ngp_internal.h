@@ -167,9 +167,15 @@ bool launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int 
 void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
                       int Bc, hipStream_t s);
+// items / bucket_counts: the chunk's items (chunk-local indices) sorted by tree size into
+// GRAD_BUCKETS groups — at most 1, 4, 8 leaves, larger — and the size of every group; null: one
+// launch for the whole chunk, sized by g.maxops
+constexpr int GRAD_BUCKETS = 4;
+inline int grad_bucket(int n_ops) { return n_ops <= 1 ? 0 : (n_ops <= 7 ? 1 : (n_ops <= 15 ? 2 : 3)); }
 void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
                           const double *alpha, const double *quad, double *partials, double *grad,
-                          double *logml, int Bc, const DevSpec &sp, hipStream_t s);
+                          double *logml, int Bc, const DevSpec &sp, hipStream_t s,
+                          const int32_t *items = nullptr, const int32_t *bucket_counts = nullptr);
 // workgroups per 64x64 tile of the gradient contraction: small launches are cut finer
 inline int grad_contract_split(long ntri, long Bc) {
     return ntri * Bc <= 1024 ? 4 : (ntri * Bc <= 2048 ? 2 : 1);

@@ -1763,13 +1763,15 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
                                                                     const double *Kinv,
                                                                     const double *alpha,
                                                                     double *partials, int ntri,
-                                                                    int split, DevSpec sp) {
+                                                                    int split, DevSpec sp,
+                                                                    const int32_t *items) {
     __shared__ DevProgram P;
     __shared__ double red[4][NGP_MAX_PARAMS + 1];
     // split: workgroups per 64x64 tile (1, 2 or 4).  A thread walks 16 / split rows; a small
     // launch (few items, short series) is latency-bound on that walk, so it is cut into more,
     // shorter workgroups (158 -> 60 us for 64 particles at n = 150).
-    const int item = blockIdx.y, tile = blockIdx.x / split, sub = blockIdx.x % split;
+    const int item = items ? items[blockIdx.y] : (int)blockIdx.y;
+    const int tile = blockIdx.x / split, sub = blockIdx.x % split;
     const int tid = threadIdx.x;
     const int nrows = 16 / split;
     load_program(&P, p.progs + item);
@@ -1937,19 +1939,24 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
 //               done);  leaves: a = vals[node], accumulate
 // so the accumulators are ga[leaf ordinal][3] and gcp[binary ordinal][2] — 38 doubles for 15
 // nodes, all static — and one LDS array [node][thread] carries values, then adjoints.
+// `items`: the chunk's items whose trees have at most NL leaves (launch_grad_contract sorts the
+// items into the instantiations by size: most trees of an ensemble are one to four leaves, and a
+// launch sized for the largest tree of the batch would run all of them at its occupancy).
 template <int NL>
 __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, ChunkPtrs p,
                                                                   const double *Kinv,
                                                                   const double *alpha,
                                                                   double *partials, int ntri,
-                                                                  int split, DevSpec sp) {
+                                                                  int split, DevSpec sp,
+                                                                  const int32_t *items) {
     constexpr int NBIN = NL - 1, NN = 2 * NL - 1;
     __shared__ DevProgram P;
     __shared__ double red[4][NGP_MAX_PARAMS + 1];
     __shared__ double cst[NN][2];
     __shared__ double vals[NN][256];
     __shared__ unsigned leaf_dec[NL], bin_dec[NBIN > 0 ? NBIN : 1];
-    const int item = blockIdx.y, tile = blockIdx.x / split, sub = blockIdx.x % split;
+    const int item = items ? items[blockIdx.y] : (int)blockIdx.y;
+    const int tile = blockIdx.x / split, sub = blockIdx.x % split;
     const int tid = threadIdx.x;
     const int nrows = 16 / split;
     load_program(&P, p.progs + item);
@@ -2534,24 +2541,39 @@ void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *a
 
 void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
                           const double *alpha, const double *quad, double *partials, double *grad,
-                          double *logml, int Bc, const DevSpec &sp, hipStream_t s) {
+                          double *logml, int Bc, const DevSpec &sp, hipStream_t s,
+                          const int32_t *items, const int32_t *bucket_counts) {
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
     int nparts = ntri;
     if (g.lattice && p.dtab) {
         const int split = grad_contract_split(ntri, Bc);
         nparts = ntri * split;
-        if (g.maxops <= 7)
-            hipLaunchKernelGGL(grad_contract_lists_kernel<4>, dim3(ntri * split, Bc), dim3(256),
-                               0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
-        else if (g.maxops <= 15)
-            hipLaunchKernelGGL(grad_contract_lists_kernel<8>, dim3(ntri * split, Bc), dim3(256),
-                               0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
-        else if (g.maxops <= LDSV_OPS)
-            hipLaunchKernelGGL(grad_contract_lattice_kernel<true>, dim3(ntri * split, Bc), dim3(256),
-                               0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
-        else
-            hipLaunchKernelGGL(grad_contract_lattice_kernel<false>, dim3(ntri * split, Bc), dim3(256),
-                               0, s, g, p, Kinv, alpha, partials, ntri, split, sp);
+        // items sorted by tree size into four launches: <= 1, <= 4, <= 8 leaves on the
+        // register-accumulator kernel, larger trees on the general one
+        const int32_t *it = items;
+        const int32_t whole[GRAD_BUCKETS] = {0, 0, g.maxops <= 15 ? Bc : 0, g.maxops <= 15 ? 0 : Bc};
+        const int32_t *cnt = items ? bucket_counts : whole;
+        for (int bk = 0; bk < GRAD_BUCKETS; ++bk) {
+            const int nb = cnt[bk];
+            if (nb <= 0) continue;
+            const dim3 grid(ntri * split, nb), blk(256);
+            if (bk == 0)
+                hipLaunchKernelGGL(grad_contract_lists_kernel<1>, grid, blk, 0, s, g, p, Kinv, alpha,
+                                   partials, ntri, split, sp, it);
+            else if (bk == 1)
+                hipLaunchKernelGGL(grad_contract_lists_kernel<4>, grid, blk, 0, s, g, p, Kinv, alpha,
+                                   partials, ntri, split, sp, it);
+            else if (bk == 2)
+                hipLaunchKernelGGL(grad_contract_lists_kernel<8>, grid, blk, 0, s, g, p, Kinv, alpha,
+                                   partials, ntri, split, sp, it);
+            else if (g.maxops <= LDSV_OPS)
+                hipLaunchKernelGGL(grad_contract_lattice_kernel<true>, grid, blk, 0, s, g, p, Kinv,
+                                   alpha, partials, ntri, split, sp, it);
+            else
+                hipLaunchKernelGGL(grad_contract_lattice_kernel<false>, grid, blk, 0, s, g, p, Kinv,
+                                   alpha, partials, ntri, split, sp, it);
+            if (it) it += nb;
+        }
     } else {
         hipLaunchKernelGGL(grad_contract_kernel, dim3(ntri, Bc), dim3(256), 0, s, g, p.progs, p.t0,
                            Kinv, alpha, partials, ntri, sp);

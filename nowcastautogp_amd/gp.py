@@ -302,6 +302,29 @@ def untransform(theta: np.ndarray, kinds: Sequence[str], prior) -> np.ndarray:
     return z
 
 
+def untransform_flat(theta: np.ndarray, codes: np.ndarray, prior) -> np.ndarray:
+    """``untransform`` for many particles at once (``theta`` / ``codes``: concatenation over
+    particles, ``KIND_CODES``): the inverse maps of ``transform_flat``."""
+    theta = np.asarray(theta, dtype=np.float64)
+    z = np.empty_like(theta)
+    m = codes == 0
+    z[m] = theta[m]
+    m = codes == 1
+    if m.any():
+        z[m] = np.log(theta[m] / (1 - theta[m]))
+    m = codes == 2
+    if m.any():
+        pr = prior["gamma"]
+        sg = theta[m] / 2.0
+        z[m] = (np.log(sg / (1 - sg)) - pr["mu"]) / pr["sigma"]
+    for code, name in ((3, "period"), (4, "wildcard")):
+        m = codes == code
+        if m.any():
+            pr = prior[name]
+            z[m] = (np.log(theta[m]) - pr["mu"]) / pr["sigma"]
+    return z
+
+
 NOISE_KIND = "wildcard"
 
 

@@ -178,14 +178,11 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
         return _forecast_with_nowcasts_batched(base_model, nowcasts, dates, draws,
                                                inv_transformation, ess_threshold)
     def clone():
-        # GPModel(deepcopy(Dict(base_model))) of the reference (src/forecasting.jl:128,133)
-        m = base_model.clone()
-        # every scenario is its own task with its own randomness in the reference
-        # (src/forecasting.jl:131-133); a clone that kept the snapshot's stream would repeat the
-        # first scenario's draws.  Splitting also advances the base model's streams, so a second
-        # call differs from the first.
-        m.reseed(int(base_model.rng_shared.integers(0, 2**62)))
-        return m
+        # GPModel(deepcopy(Dict(base_model))) of the reference (src/forecasting.jl:128,133).  Every
+        # scenario is its own task with its own randomness there (:131-133); a clone that kept the
+        # snapshot's streams would repeat the first scenario's draws.  Splitting also advances the
+        # base model's shared stream, so a second call differs from the first.
+        return base_model.clone(root=int(base_model.rng_shared.integers(0, 2**62)))
 
     if lockstep and same_dates:
         # the reference's D tasks as ONE ensemble of P x D items (src/forecasting.jl:131-159)

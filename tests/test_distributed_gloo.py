@@ -198,8 +198,14 @@ def test_sharded_forecast_with_nowcasts_batches_scenarios_and_reproduces_one_ran
 
 
 def test_shard_partition_covers_everything():
+    from nowcastautogp_amd import _lib
     from nowcastautogp_amd.distributed import shard
     for P in (1, 7, 64, 257):
         for size in (1, 2, 3, 8):
             idx = np.concatenate([np.arange(P)[shard(P, r, size)] for r in range(size)])
             assert np.array_equal(idx, np.arange(P))
+            # the C-ABI's collective (ngp_weights_allgather_normalize) partitions the same way
+            for r in range(size):
+                if P >= size:
+                    sl = shard(P, r, size)
+                    assert _lib.shard(P, size, r) == (sl.start, sl.stop - sl.start)
