@@ -458,9 +458,21 @@ function GPModel(ds::AbstractVector{<:Dates.TimeType}, y::AbstractVector{<:Real}
                    -ys * (yhi + ylo) / 2, depth_cap, rng, ctx)
 end
 
+"""
+Model time of dates: `slope * (days - origin)`.  The subtraction of day numbers is exact, so dates
+whole days apart land on an exact lattice — which the library needs to replace the transcendentals
+of the kernel grammar by table lookups; `slope * days + intercept` on day numbers of ~7e5 loses
+eleven digits to cancellation (nowcastautogp_amd/autogp.py `DateTransform`).
+"""
+function _model_time(m::GPModel, ds)
+    o = -m.ds_intercept / m.ds_slope
+    abs(o - round(o)) < 1.0e-6 && (o = round(o))
+    return m.ds_slope .* (_days(ds) .- o)
+end
+
 function _obs(m::GPModel, count::Int = m.n_obs)
     idx = sort(m.perm[1:count])
-    return m.ds_slope .* _days(m.ds[idx]) .+ m.ds_intercept, m.y_slope .* m.y[idx] .+ m.y_intercept
+    return _model_time(m, m.ds[idx]), m.y_slope .* m.y[idx] .+ m.y_intercept
 end
 
 module Schedule
@@ -699,7 +711,7 @@ function add_data_lockstep!(ms::Vector{GPModel}, ds::AbstractVector{<:Dates.Time
     length(ys) == length(ms) && all(length(y) == length(ds) for y in ys) ||
         throw(ArgumentError("one vector of length(ds) observations per model"))
     t, y = _obs(base)
-    t_add = base.ds_slope .* _days(ds) .+ base.ds_intercept
+    t_add = _model_time(base, ds)
     y_add = reduce(hcat, (base.y_slope .* Float64.(v) .+ base.y_intercept for v in ys))   # d x D
     o = factor === nothing ? nowcast_batch(base.ctx, base.particles, t, y, t_add, y_add, Float64[]) :
                              nowcast(factor, t_add, y_add, Float64[])
@@ -753,7 +765,7 @@ end
 function predict_mvn_lockstep(ms::Vector{GPModel}, dates::AbstractVector{<:Dates.TimeType})
     t, ys = _group_obs(ms)
     _check_horizon(length(t), length(dates))
-    t_new = ms[1].ds_slope .* _days(dates) .+ ms[1].ds_intercept
+    t_new = _model_time(ms[1], dates)
     progs = reduce(vcat, (m.particles for m in ms))
     owner = [j for (j, m) in enumerate(ms) for _ in m.particles]
     mu, sigma, _, info = predict_batch(ms[1].ctx, progs, t, _item_y(ys, owner), t_new)

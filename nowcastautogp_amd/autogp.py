@@ -144,10 +144,36 @@ class LinearTransform:
         return (np.asarray(x, dtype=np.float64) - self.intercept) / self.slope
 
 
-def _ds_transform(days: np.ndarray) -> LinearTransform:
+@dataclass
+class DateTransform(LinearTransform):
+    """The affine map days -> model time, applied as ``slope * (days - origin)``: the subtraction
+    of two day numbers is exact, so dates that are whole days apart land on an exact lattice
+    ``q * slope`` — which is what lets the library replace every transcendental of the kernel
+    grammar by table lookups (``detect_lattice`` in csrc/ngp_api.hip accepts a few ulp of
+    deviation).  ``slope * days + intercept`` on day numbers of ~7e5 loses eleven digits to
+    cancellation and every job of a fitted model took the direct-evaluation kernels."""
+    origin: float = 0.0
+
+    def apply(self, x):
+        return self.slope * (np.asarray(x, dtype=np.float64) - self.origin)
+
+    def invert(self, x):
+        return np.asarray(x, dtype=np.float64) / self.slope + self.origin
+
+
+def date_transform(slope: float, intercept: float) -> DateTransform:
+    """From the wire's (slope, intercept): the origin is -intercept / slope, a whole day number
+    whenever the dates are (then recovered exactly by rounding)."""
+    origin = -intercept / slope
+    if abs(origin - round(origin)) < 1e-6:
+        origin = float(round(origin))
+    return DateTransform(slope, intercept, origin)
+
+
+def _ds_transform(days: np.ndarray) -> DateTransform:
     lo, hi = float(days.min()), float(days.max())
     span = hi - lo if hi > lo else 1.0
-    return LinearTransform(1.0 / span, -lo / span)
+    return DateTransform(1.0 / span, -lo / span, lo)
 
 
 def _y_transform(y: np.ndarray) -> LinearTransform:
@@ -327,7 +353,7 @@ class GPModel:
         m.config = copy.deepcopy(self.config)
         m.ds = list(self.ds)
         m.y, m.days = self.y.copy(), self.days.copy()
-        m.ds_transform = LinearTransform(self.ds_transform.slope, self.ds_transform.intercept)
+        m.ds_transform = copy.copy(self.ds_transform)
         m.y_transform = LinearTransform(self.y_transform.slope, self.y_transform.intercept)
         m.depth_cap = self.depth_cap
         m._root, m._gen = self._root, self._gen

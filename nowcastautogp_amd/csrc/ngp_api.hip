@@ -1627,7 +1627,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         });
         // the chunk's items sorted by tree size: every size class runs on the contraction kernel
         // sized for it
-        int32_t counts[GRAD_BUCKETS] = {0, 0, 0, 0};
+        int32_t counts[GRAD_BUCKETS] = {};
         {
             for (int i = 0; i < bc; ++i) ++counts[grad_bucket(kernels[b0 + i].n_ops)];
             int32_t pos[GRAD_BUCKETS], acc = 0;

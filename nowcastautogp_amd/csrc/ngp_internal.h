@@ -168,10 +168,12 @@ void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipS
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
                       int Bc, hipStream_t s);
 // items / bucket_counts: the chunk's items (chunk-local indices) sorted by tree size into
-// GRAD_BUCKETS groups — at most 1, 4, 8 leaves, larger — and the size of every group; null: one
-// launch for the whole chunk, sized by g.maxops
-constexpr int GRAD_BUCKETS = 4;
-inline int grad_bucket(int n_ops) { return n_ops <= 1 ? 0 : (n_ops <= 7 ? 1 : (n_ops <= 15 ? 2 : 3)); }
+// GRAD_BUCKETS groups — at most 1, 2, 4, 8, 16 leaves, larger — and the size of every group;
+// null: one launch for the whole chunk, sized by g.maxops
+constexpr int GRAD_BUCKETS = 6;
+inline int grad_bucket(int n_ops) {
+    return n_ops <= 1 ? 0 : n_ops <= 3 ? 1 : n_ops <= 7 ? 2 : n_ops <= 15 ? 3 : n_ops <= 31 ? 4 : 5;
+}
 void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
                           const double *alpha, const double *quad, double *partials, double *grad,
                           double *logml, int Bc, const DevSpec &sp, hipStream_t s,

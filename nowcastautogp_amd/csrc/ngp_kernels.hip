@@ -30,6 +30,8 @@
 //   D: lane l, register r holds D[m = (l>>4) + 4 r][n = l&15]
 // so a D-layout tile is directly the B operand of a following product that sums over its row
 // index (register r <-> k-slot), which is what keeps the triangular solve in registers.
+#include <type_traits>
+
 #include "ngp_internal.h"
 #include "ngp_mfma.h"
 #include "ngp_col_kernels.h"
@@ -1942,7 +1944,22 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
 // `items`: the chunk's items whose trees have at most NL leaves (launch_grad_contract sorts the
 // items into the instantiations by size: most trees of an ensemble are one to four leaves, and a
 // launch sized for the largest tree of the batch would run all of them at its occupancy).
-template <int NL>
+// f(std::integral_constant<int, I>) for I = FROM, FROM - 1, ..., 0: an unrolled loop by construction
+// (where `#pragma unroll` is a request hipcc may decline, indices here ARE compile-time constants)
+template <int FROM, class F>
+__device__ __forceinline__ void static_for_down(F &&f) {
+    if constexpr (FROM >= 0) {
+        f(std::integral_constant<int, FROM>{});
+        static_for_down<FROM - 1>(f);
+    }
+}
+
+// NACC / PASS: trees of more than 8 leaves would need more accumulators than the register file holds
+// beside the sweeps; they run the kernel several times (PASS = 0, 1, ...), every pass sweeping all
+// nodes but accumulating only the leaves / binaries with ordinal in [PASS NACC, (PASS + 1) NACC) — the
+// first pass writes the partial sums, the later ones add theirs (same thread, same address, stream
+// order).  Twice the sweep arithmetic, still no scratch.
+template <int NL, int NACC = NL, int PASS = 0>
 __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, ChunkPtrs p,
                                                                   const double *Kinv,
                                                                   const double *alpha,
@@ -1950,6 +1967,7 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
                                                                   int split, DevSpec sp,
                                                                   const int32_t *items) {
     constexpr int NBIN = NL - 1, NN = 2 * NL - 1;
+    constexpr bool PREFETCH = NL <= 8;     // 4 NL + 2 NBIN more doubles in registers
     __shared__ DevProgram P;
     __shared__ double red[4][NGP_MAX_PARAMS + 1];
     __shared__ double cst[NN][2];
@@ -1960,6 +1978,7 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     const int tid = threadIdx.x;
     const int nrows = 16 / split;
     load_program(&P, p.progs + item);
+    for (int i = tid; i < 4 * (NGP_MAX_PARAMS + 1); i += 256) (&red[0][0])[i] = 0.0;
     __syncthreads();
     if (tid < 64) {   // one wave: node i -> its list and its constants
         const int i = tid;
@@ -2010,21 +2029,19 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     const double *tab = p.tab + (long)item * g.maxstat * R;
     const double *dt = p.dtab + (long)item * g.maxstat * 3 * R;
     const double *sig = p.sig + (long)item * g.maxcp * npts;
-    unsigned ld_[NL], bd_[NBIN > 0 ? NBIN : 1];
-#pragma unroll
-    for (int l = 0; l < NL; ++l) ld_[l] = (unsigned)__builtin_amdgcn_readfirstlane((int)leaf_dec[l]);
-#pragma unroll
-    for (int b = 0; b < NBIN; ++b) bd_[b] = (unsigned)__builtin_amdgcn_readfirstlane((int)bin_dec[b]);
+    // the decoded lists stay in LDS and are read as scalars where they are used (private copies
+    // would sit in scratch wherever hipcc declines to unroll a sweep completely)
+    auto LD = [&](int l) { return (unsigned)__builtin_amdgcn_readfirstlane((int)leaf_dec[l]); };
+    auto BD = [&](int b) { return (unsigned)__builtin_amdgcn_readfirstlane((int)bin_dec[b]); };
     auto f_node = [](unsigned d) { return (int)(d & 31u); };
     auto f_op = [](unsigned d) { return (int)((d >> 5) & 15u); };
     auto f_po = [](unsigned d) { return (int)((d >> 9) & 255u); };
     auto f_slot = [](unsigned d) { return (int)((d >> 17) & 255u); };
     auto f_first = [](unsigned d) { return (int)(d >> 25); };
-    double ga[NL][3], gcp[NBIN > 0 ? NBIN : 1][2];
+    double ga[NACC][3], gcp[NACC][2];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) ga[l][0] = ga[l][1] = ga[l][2] = 0.0;
-#pragma unroll
-    for (int b = 0; b < NBIN; ++b) gcp[b][0] = gcp[b][1] = 0.0;
+    for (int l = 0; l < NACC; ++l) ga[l][0] = ga[l][1] = ga[l][2] = gcp[l][0] = gcp[l][1] = 0.0;
+    constexpr auto own = [](int ordinal) { return ordinal / NACC == PASS; };
     double gnoise = 0.0;
     const double *Ki = Kinv + (long)item * g.n0 * g.n0;
     const double *al = alpha + (long)item * g.n0;
@@ -2043,41 +2060,71 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
             const double t1 = p.t0[row];
             const double d = fabs(t1 - t2);
             const int dq = abs(p.qpts[row] - q2);
+            // ---- every table value of this element requested up front (PREFETCH): read where
+            //      the sweeps use them, each leaf's lookups wait out their own round trip — four or
+            //      five dependent memory latencies per element, which is what the kernel's time was
+            //      (2.3 us per row of a wave at two leaves).  Together they cost one.
+            double tv[PREFETCH ? NL : 1], td[PREFETCH ? NL : 1][3], sg[PREFETCH && NBIN ? NBIN : 1][2];
+            if constexpr (PREFETCH) {
+                static_for_down<NL - 1>([&](auto lc) {
+                    constexpr int l = decltype(lc)::value;
+                    if (l >= nl) return;
+                    const int op = f_op(LD(l));
+                    if (op > NGP_OP_LINEAR) {      // a stationary leaf: value and derivative factors
+                        const long sl = f_slot(LD(l));
+                        const double *d0 = dt + sl * 3 * R + dq;
+                        tv[l] = tab[sl * R + dq];
+                        td[l][0] = d0[0];
+                        td[l][1] = d0[R];
+                        td[l][2] = d0[2 * R];
+                    }
+                });
+                static_for_down<NBIN - 1>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    if (b >= nbin) return;
+                    const int op = f_op(BD(b));
+                    if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
+                        sg[b][0] = sig[(long)f_slot(BD(b)) * npts + row];
+                        sg[b][1] = sig[(long)f_slot(BD(b)) * npts + col];
+                    }
+                });
+            }
             // ---- forward: leaves, then binary nodes in postfix order
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                if (l >= nl) break;
-                const int op = f_op(ld_[l]), po = f_po(ld_[l]);
+            static_for_down<NL - 1>([&](auto lc) {
+                constexpr int l = decltype(lc)::value;
+                if (l >= nl) return;
+                const int op = f_op(LD(l)), po = f_po(LD(l));
                 double v;
                 if (op == NGP_OP_CONSTANT) v = P.params[po];
                 else if (op == NGP_OP_LINEAR)
                     v = P.params[po + 1] + P.params[po + 2] * (t1 - P.params[po]) * (t2 - P.params[po]);
-                else v = tab[(long)f_slot(ld_[l]) * R + dq];
-                vals[f_node(ld_[l])][tid] = v;
-            }
-#pragma unroll
-            for (int b = 0; b < NBIN; ++b) {
-                if (b >= nbin) break;
-                const int op = f_op(bd_[b]), nd = f_node(bd_[b]);
-                const double x = vals[f_first(bd_[b])][tid], y = vals[nd - 1][tid];
+                else if constexpr (PREFETCH) v = tv[l];
+                else v = tab[(long)f_slot(LD(l)) * R + dq];
+                vals[f_node(LD(l))][tid] = v;
+            });
+            static_for_down<NBIN - 1>([&](auto bc) {
+                constexpr int b = NBIN - 1 - decltype(bc)::value;       // ascending: postfix order
+                if (b >= nbin) return;
+                const int op = f_op(BD(b)), nd = f_node(BD(b));
+                const double x = vals[f_first(BD(b))][tid], y = vals[nd - 1][tid];
                 double v;
                 if (op == NGP_OP_PLUS) v = x + y;
                 else if (op == NGP_OP_TIMES) v = x * y;
                 else {
                     const double kl = (op == NGP_OP_CHANGEPOINT) ? x : y;
                     const double kr = (op == NGP_OP_CHANGEPOINT) ? y : x;
-                    const double g1 = sig[(long)f_slot(bd_[b]) * npts + row];
-                    const double g2 = sig[(long)f_slot(bd_[b]) * npts + col];
+                    const double g1 = PREFETCH ? sg[b][0] : sig[(long)f_slot(BD(b)) * npts + row];
+                    const double g2 = PREFETCH ? sg[b][1] : sig[(long)f_slot(BD(b)) * npts + col];
                     v = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
                 }
                 vals[nd][tid] = v;
-            }
+            });
             // ---- reverse: the root's adjoint is w; adjoints overwrite values on the way down
             vals[nops - 1][tid] = w;
-#pragma unroll
-            for (int b = NBIN - 1; b >= 0; --b) {
-                if (b >= nbin) continue;
-                const int op = f_op(bd_[b]), nd = f_node(bd_[b]), fi = f_first(bd_[b]);
+            static_for_down<NBIN - 1>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                if (b >= nbin) return;
+                const int op = f_op(BD(b)), nd = f_node(BD(b)), fi = f_first(BD(b));
                 const double a = vals[nd][tid];
                 const double x = vals[fi][tid], y = vals[nd - 1][tid];
                 double ax, ay;   // adjoints of the first-evaluated and the second operand
@@ -2088,57 +2135,60 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
                 } else {
                     const bool nat = (op == NGP_OP_CHANGEPOINT);
                     const double kl = nat ? x : y, kr = nat ? y : x;
-                    const int po = f_po(bd_[b]);
+                    const int po = f_po(BD(b));
                     const double loc = P.params[po];
                     const double us = cst[nd][0], isc = cst[nd][1];   // u = us (t - loc), 1 / scale
                     const double u1 = us * (t1 - loc), u2 = us * (t2 - loc);
-                    const double g1 = sig[(long)f_slot(bd_[b]) * npts + row];
-                    const double g2 = sig[(long)f_slot(bd_[b]) * npts + col];
+                    const double g1 = PREFETCH ? sg[b][0] : sig[(long)f_slot(BD(b)) * npts + row];
+                    const double g2 = PREFETCH ? sg[b][1] : sig[(long)f_slot(BD(b)) * npts + col];
                     const double q1 = 2.0 * g1 * (1.0 - g1), q2_ = 2.0 * g2 * (1.0 - g2);
                     const double d1l = -q1 * us, d2l = -q2_ * us;
                     const double d1s = -q1 * u1 * isc, d2s = -q2_ * u2 * isc;
-                    gcp[b][0] += a * (d1l * kl * g2 + g1 * kl * d2l - d1l * kr * (1.0 - g2) -
-                                      (1.0 - g1) * kr * d2l);
-                    gcp[b][1] += a * (d1s * kl * g2 + g1 * kl * d2s - d1s * kr * (1.0 - g2) -
-                                      (1.0 - g1) * kr * d2s);
+                    if (own(b)) {
+                        gcp[b % NACC][0] += a * (d1l * kl * g2 + g1 * kl * d2l -
+                                                 d1l * kr * (1.0 - g2) - (1.0 - g1) * kr * d2l);
+                        gcp[b % NACC][1] += a * (d1s * kl * g2 + g1 * kl * d2s -
+                                                 d1s * kr * (1.0 - g2) - (1.0 - g1) * kr * d2s);
+                    }
                     const double al_ = a * g1 * g2, ar_ = a * (1.0 - g1) * (1.0 - g2);
                     ax = nat ? al_ : ar_;
                     ay = nat ? ar_ : al_;
                 }
                 vals[fi][tid] = ax;
                 vals[nd - 1][tid] = ay;
-            }
-#pragma unroll
-            for (int l = 0; l < NL; ++l) {
-                if (l >= nl) break;
-                const int op = f_op(ld_[l]), po = f_po(ld_[l]), nd = f_node(ld_[l]);
+            });
+            static_for_down<NL - 1>([&](auto lc) {
+                constexpr int l = decltype(lc)::value;
+                if (l >= nl || !own(l)) return;
+                const int op = f_op(LD(l)), po = f_po(LD(l)), nd = f_node(LD(l));
                 const double a = vals[nd][tid];
                 if (op == NGP_OP_CONSTANT) {
-                    ga[l][0] += a;
+                    ga[l % NACC][0] += a;
                 } else if (op == NGP_OP_LINEAR) {
                     const double cc = P.params[po], a1 = t1 - cc, a2 = t2 - cc;
-                    ga[l][0] += a * P.params[po + 2] * (-a1 - a2);
-                    ga[l][1] += a;
-                    ga[l][2] += a * a1 * a2;
+                    ga[l % NACC][0] += a * P.params[po + 2] * (-a1 - a2);
+                    ga[l % NACC][1] += a;
+                    ga[l % NACC][2] += a * a1 * a2;
                 } else {
-                    const double *d0 = dt + (long)f_slot(ld_[l]) * 3 * R + dq;
-                    const double e = d0[0];
+                    const double *d0 = dt + (long)f_slot(LD(l)) * 3 * R + dq;
+                    const double e = PREFETCH ? td[l][0] : d0[0];
+                    const double f1 = PREFETCH ? td[l][1] : d0[R], f2 = PREFETCH ? td[l][2] : d0[2 * R];
                     const double c0 = cst[nd][0], c1 = cst[nd][1];
                     if (op == NGP_OP_SQEXP) {
-                        ga[l][0] += a * e * d * d * c0;
-                        ga[l][1] += a * e;
+                        ga[l % NACC][0] += a * e * d * d * c0;
+                        ga[l % NACC][1] += a * e;
                     } else if (op == NGP_OP_GAMMAEXP) {
-                        ga[l][0] += a * c0 * d0[R];
-                        ga[l][1] -= a * c1 * d0[2 * R];
-                        ga[l][2] += a * e;
+                        ga[l % NACC][0] += a * c0 * f1;
+                        ga[l % NACC][1] -= a * c1 * f2;
+                        ga[l % NACC][2] += a * e;
                     } else {
-                        ga[l][0] += a * c0 * d0[R];
-                        ga[l][1] += a * c1 * d0[2 * R];
-                        ga[l][2] += a * e;
+                        ga[l % NACC][0] += a * c0 * f1;
+                        ga[l % NACC][1] += a * c1 * f2;
+                        ga[l % NACC][2] += a * e;
                     }
                 }
-            }
-            if (row == col) gnoise += w;   // d K / d noise = I (w already carries the 1/2)
+            });
+            if (PASS == 0 && row == col) gnoise += w;   // d K / d noise = I (w carries the 1/2)
         }
     }
     // ---- deterministic reduction: wave shuffles per (node, parameter), then the four waves in order
@@ -2148,37 +2198,40 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         return v;
     };
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        if (l >= nl) break;
-        const int op = f_op(ld_[l]);
+    static_for_down<NL - 1>([&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        if (l >= nl || !own(l)) return;
+        const int op = f_op(LD(l));
         const int cnt = op == NGP_OP_CONSTANT ? 1 : (op == NGP_OP_SQEXP ? 2 : 3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (k >= cnt) break;
-            const double v = wave_sum(ga[l][k]);
-            if (lane == 0) red[wave][f_po(ld_[l]) + k] = v;
+            const double v = wave_sum(ga[l % NACC][k]);
+            if (lane == 0) red[wave][f_po(LD(l)) + k] = v;
         }
-    }
-#pragma unroll
-    for (int b = 0; b < NBIN; ++b) {
-        if (b >= nbin) break;
-        const int op = f_op(bd_[b]);
-        if (op != NGP_OP_CHANGEPOINT && op != OP_CP_SWAPPED) continue;
+    });
+    static_for_down<NBIN - 1>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        if (b >= nbin) return;
+        const int op = f_op(BD(b));
+        if ((op != NGP_OP_CHANGEPOINT && op != OP_CP_SWAPPED) || !own(b)) return;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const double v = wave_sum(gcp[b][k]);
-            if (lane == 0) red[wave][f_po(bd_[b]) + k] = v;
+            const double v = wave_sum(gcp[b % NACC][k]);
+            if (lane == 0) red[wave][f_po(BD(b)) + k] = v;
         }
-    }
-    {
+    });
+    if (PASS == 0) {
         const double v = wave_sum(gnoise);
         if (lane == 0) red[wave][np] = v;
     }
     __syncthreads();
-    if (tid <= np)
-        partials[((long)item * ntri * split + blockIdx.x) * (NGP_MAX_PARAMS + 1) + tid] =
-            red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid <= np) {
+        double *dst = partials + ((long)item * ntri * split + blockIdx.x) * (NGP_MAX_PARAMS + 1) + tid;
+        const double sum = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (PASS == 0) *dst = sum;
+        else *dst += sum;      // a parameter of another pass adds 0.0: its bits do not change
+    }
 }
 
 __global__ __launch_bounds__(128) void grad_reduce_kernel(JobGeom g, const DevProgram *progs,
@@ -2548,30 +2601,33 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
     if (g.lattice && p.dtab) {
         const int split = grad_contract_split(ntri, Bc);
         nparts = ntri * split;
-        // items sorted by tree size into four launches: <= 1, <= 4, <= 8 leaves on the
-        // register-accumulator kernel, larger trees on the general one
+        // items sorted by tree size (grad_bucket): 1, 2, 4, 8 leaves on the register-accumulator
+        // kernel, up to 16 leaves in two passes of it, larger trees on the general kernel
         const int32_t *it = items;
-        const int32_t whole[GRAD_BUCKETS] = {0, 0, g.maxops <= 15 ? Bc : 0, g.maxops <= 15 ? 0 : Bc};
+        int32_t whole[GRAD_BUCKETS] = {};
+        whole[grad_bucket(g.maxops)] = Bc;
         const int32_t *cnt = items ? bucket_counts : whole;
         for (int bk = 0; bk < GRAD_BUCKETS; ++bk) {
             const int nb = cnt[bk];
             if (nb <= 0) continue;
             const dim3 grid(ntri * split, nb), blk(256);
-            if (bk == 0)
-                hipLaunchKernelGGL(grad_contract_lists_kernel<1>, grid, blk, 0, s, g, p, Kinv, alpha,
-                                   partials, ntri, split, sp, it);
-            else if (bk == 1)
-                hipLaunchKernelGGL(grad_contract_lists_kernel<4>, grid, blk, 0, s, g, p, Kinv, alpha,
-                                   partials, ntri, split, sp, it);
-            else if (bk == 2)
-                hipLaunchKernelGGL(grad_contract_lists_kernel<8>, grid, blk, 0, s, g, p, Kinv, alpha,
-                                   partials, ntri, split, sp, it);
-            else if (g.maxops <= LDSV_OPS)
+#define NGP_LAUNCH_LISTS(...)                                                                    \
+    hipLaunchKernelGGL((grad_contract_lists_kernel<__VA_ARGS__>), grid, blk, 0, s, g, p, Kinv, alpha, \
+                       partials, ntri, split, sp, it)
+            if (bk == 0) NGP_LAUNCH_LISTS(1);
+            else if (bk == 1) NGP_LAUNCH_LISTS(2);
+            else if (bk == 2) NGP_LAUNCH_LISTS(4);
+            else if (bk == 3) NGP_LAUNCH_LISTS(8);
+            else if (bk == 4) {   // 9 .. 16 leaves: two passes of eight accumulator sets
+                NGP_LAUNCH_LISTS(16, 8, 0);
+                NGP_LAUNCH_LISTS(16, 8, 1);
+            } else if (g.maxops <= LDSV_OPS)
                 hipLaunchKernelGGL(grad_contract_lattice_kernel<true>, grid, blk, 0, s, g, p, Kinv,
                                    alpha, partials, ntri, split, sp, it);
             else
                 hipLaunchKernelGGL(grad_contract_lattice_kernel<false>, grid, blk, 0, s, g, p, Kinv,
                                    alpha, partials, ntri, split, sp, it);
+#undef NGP_LAUNCH_LISTS
             if (it) it += nb;
         }
     } else {

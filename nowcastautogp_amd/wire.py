@@ -166,8 +166,8 @@ def model_from_wire(model, d: Dict[str, Any]) -> None:
     model.ds = _ds_from_wire(d["data"]["ds_kind"], d["data"]["ds"])
     model.y = np.array(d["data"]["y"], dtype=np.float64)
     model.days = autogp.to_days(model.ds)
-    model.ds_transform = autogp.LinearTransform(d["transforms"]["ds"]["slope"],
-                                                d["transforms"]["ds"]["intercept"])
+    model.ds_transform = autogp.date_transform(d["transforms"]["ds"]["slope"],
+                                               d["transforms"]["ds"]["intercept"])
     model.y_transform = autogp.LinearTransform(d["transforms"]["y"]["slope"],
                                                d["transforms"]["y"]["intercept"])
     model.depth_cap = int(d["depth_cap"])
