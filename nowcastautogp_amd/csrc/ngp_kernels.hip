@@ -1482,15 +1482,20 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_kernel(JobGeom g, const doub
 // of four (the fat step's order) where gemm_rows takes even then odd k of an 8-column stage: the
 // two kernels agree to rounding, not bit for bit.  Block pairs with bi >= bj; the tile above the
 // diagonal in a diagonal block is computed and dropped.
+// Grid: 1-D, workgroups b and b + 8 share an XCD (round-robin dispatch), and all blocks of an item
+// go to one XCD: the 136 blocks of an item at n = 2048 read its 18 MB of W thirteen times over
+// (PMC: 200 MB of fetches per item, 3.2 TB/s) and only an L2 they share can absorb that.
 __global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const double *L,
-                                                               double *Kinv, int nblk) {
+                                                               double *Kinv, int nblk, int Bc) {
     constexpr int ROWB = 128, BLKB = 8 * ROWB + 128, STAGE = 32 * BLKB;
     auto row_off = [](int row) { return (row >> 3) * BLKB + (row & 7) * ROWB; };
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    const int item = blockIdx.y;
-    const int pr = blockIdx.x;
-    if (pr >= nblk) return;
+    const int wg = blockIdx.x;
+    const int xcd = wg & 7, idx = wg >> 3;
+    const int item = (idx / nblk) * 8 + xcd;
+    const int pr = idx % nblk;
+    if (item >= Bc) return;
     int bi = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= pr) ++bi;
     while (bi * (bi + 1) / 2 > pr) --bi;
@@ -2583,7 +2588,8 @@ void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *a
     const int npairs = g.nb0 * (g.nb0 + 1) / 2;
     if (g.nb0 >= 8) {   // long series: 2 x 2 tile blocks staged through LDS (HBM traffic halves)
         const int nb2 = (g.nb0 + 1) / 2, nblk = nb2 * (nb2 + 1) / 2;
-        hipLaunchKernelGGL(grad_kinv_lds_kernel, dim3(nblk, Bc), dim3(256), 0, s, g, L, Kinv, nblk);
+        hipLaunchKernelGGL(grad_kinv_lds_kernel, dim3(nblk * ((Bc + 7) / 8 * 8)), dim3(256), 0, s, g, L,
+                           Kinv, nblk, Bc);
     } else {
         hipLaunchKernelGGL(grad_kinv_kernel, dim3((npairs + 3) / 4, Bc), dim3(256), 0, s, g, L, Kinv,
                            npairs);
