@@ -575,11 +575,14 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
     codes = np.array(codes_l)
     z0 = gp.untransform_flat(np.concatenate(theta0), codes, prior)
     last = off[1:] - 1                                       # the noise latent of every item
-    positive = (codes == gp.KIND_CODES["wildcard"]) | (codes == gp.KIND_CODES["period"])
-    is_gamma, is_unit = codes == gp.KIND_CODES["gamma"], codes == gp.KIND_CODES["unit"]
+    i_positive = np.flatnonzero((codes == gp.KIND_CODES["wildcard"]) | (codes == gp.KIND_CODES["period"]))
+    i_gamma = np.flatnonzero(codes == gp.KIND_CODES["gamma"])
+    i_unit = np.flatnonzero(codes == gp.KIND_CODES["unit"])
+    to_theta = gp.FlatTransform(codes, prior)
 
     is_param = np.ones(codes.size, dtype=bool)
     is_param[last] = False
+    i_param = np.flatnonzero(is_param)
     eng = models[0]._eng()
     if Y is None:     # the callers that make several moves on the same data pass it in
         Y = _item_y(ys, [j for j, _ in items])
@@ -591,16 +594,19 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
         return np.bincount(seg, weights=v, minlength=B)
 
     def potential(z):
-        th, dth = gp.transform_flat(np.nan_to_num(z, nan=0.0, posinf=50.0, neginf=-50.0), codes,
-                                    prior)
+        zc = z if np.isfinite(z).all() else np.nan_to_num(z, nan=0.0, posinf=50.0, neginf=-50.0)
+        th, dth = to_theta(zc)
         # degenerate parameters (a diverged trajectory) would only produce a non-PD matrix and a
         # rejection; keep them inside what the kernels accept
         th = np.clip(th, -1e6, 1e6)
-        th[positive] = np.maximum(th[positive], 1e-12)
-        th[is_gamma] = np.clip(th[is_gamma], 1e-9, 2.0 - 1e-9)
-        th[is_unit] = np.clip(th[is_unit], 1e-9, 1.0 - 1e-9)
+        if i_positive.size:
+            th[i_positive] = np.maximum(th[i_positive], 1e-12)
+        if i_gamma.size:
+            th[i_gamma] = np.clip(th[i_gamma], 1e-9, 2.0 - 1e-9)
+        if i_unit.size:
+            th[i_unit] = np.clip(th[i_unit], 1e-9, 1.0 - 1e-9)
         if ka is not None:      # same structures, new parameters: refill the C array in place
-            ka.set_params(th[is_param], th[last])
+            ka.set_params(th[i_param], th[last])
             lm, g, info = eng.logml_grad_flat(ka, t, Y)
         else:
             progs = [(ops[i], th[sl[i]][:-1], float(th[last[i]])) for i in range(B)]
@@ -628,7 +634,7 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
         pm = pm - (eps if step < n_leapfrog - 1 else 0.5 * eps) * dU
     with np.errstate(invalid="ignore", over="ignore"):
         H1 = U1 + 0.5 * sums(pm * pm)
-    th_new, _ = gp.transform_flat(z, codes, prior)
+    th_new, _ = to_theta(z)
     acc = 0
     for i, (j, k) in enumerate(items):
         u = prng[i].random()      # drawn for every particle: the stream does not depend on H

@@ -302,6 +302,48 @@ def untransform(theta: np.ndarray, kinds: Sequence[str], prior) -> np.ndarray:
     return z
 
 
+class FlatTransform:
+    """``transform_flat`` for a FIXED set of latents, everything that does not depend on z worked
+    out once: an HMC move evaluates the map a dozen times on the same hundred-odd latents, and at
+    that size the cost of a call is the number of numpy operations, not their length (the 24-particle
+    calls of a vignette-scale fit spent as long in this map as the device spent on the call).
+    Same formulas, same operation order, same clamping as ``transform_flat``: bit-identical."""
+
+    def __init__(self, codes: np.ndarray, prior):
+        codes = np.asarray(codes)
+        n = codes.size
+        self.a, self.b = np.zeros(n), np.ones(n)
+        self.scale = np.ones(n)
+        for code, name in ((2, "gamma"), (3, "period"), (4, "wildcard")):
+            m = codes == code
+            self.a[m], self.b[m] = prior[name]["mu"], prior[name]["sigma"]
+        self.scale[codes == 2] = 2.0
+        self.i_real = np.flatnonzero(codes == 0)
+        self.i_sig = np.flatnonzero((codes == 1) | (codes == 2))
+        self.i_exp = np.flatnonzero((codes == 3) | (codes == 4))
+        self.a_sig, self.b_sig, self.s_sig = self.a[self.i_sig], self.b[self.i_sig], self.scale[self.i_sig]
+        self.a_exp, self.b_exp = self.a[self.i_exp], self.b[self.i_exp]
+
+    def __call__(self, z: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        th = np.empty_like(z)
+        dth = np.empty_like(z)
+        if self.i_real.size:
+            th[self.i_real] = z[self.i_real]
+            dth[self.i_real] = 1.0
+        if self.i_sig.size:
+            x = np.clip(self.a_sig + self.b_sig * z[self.i_sig], -700.0, 700.0)
+            e = np.exp(-np.abs(x))
+            sg = np.where(x >= 0, 1.0 / (1.0 + e), e / (1.0 + e))
+            ssg = self.s_sig * sg
+            th[self.i_sig] = ssg
+            dth[self.i_sig] = ssg * (1 - sg) * self.b_sig
+        if self.i_exp.size:
+            v = np.exp(np.clip(self.a_exp + self.b_exp * z[self.i_exp], -300.0, 300.0))
+            th[self.i_exp] = v
+            dth[self.i_exp] = v * self.b_exp
+        return th, dth
+
+
 def untransform_flat(theta: np.ndarray, codes: np.ndarray, prior) -> np.ndarray:
     """``untransform`` for many particles at once (``theta`` / ``codes``: concatenation over
     particles, ``KIND_CODES``): the inverse maps of ``transform_flat``."""

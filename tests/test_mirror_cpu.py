@@ -147,6 +147,12 @@ def test_transform_flat_equals_the_per_particle_transform():
     ref = [gp.transform(z, kd, cfg.prior) for z, kd in zip(zs, kinds)]
     assert np.allclose(th, np.concatenate([r[0] for r in ref]), rtol=1e-14, atol=0)
     assert np.allclose(dth, np.concatenate([r[1] for r in ref]), rtol=1e-13, atol=1e-300)
+    # the per-move form (index sets and prior parameters worked out once): bit-identical
+    th2, dth2 = gp.FlatTransform(codes, cfg.prior)(np.concatenate(zs))
+    assert np.array_equal(th2, th) and np.array_equal(dth2, dth)
+    back = gp.untransform_flat(th2, codes, cfg.prior)
+    ok = np.abs(np.concatenate(zs)) < 20
+    assert np.allclose(back[ok], np.concatenate(zs)[ok], rtol=1e-6, atol=1e-6)
 
 
 def test_identical_scenarios_get_independent_draws_and_calls_differ(eng):
