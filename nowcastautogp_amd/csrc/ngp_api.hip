@@ -486,6 +486,12 @@ struct ngp_job {
     double *logml_base = nullptr, *logml_full = nullptr, *mu = nullptr, *sigma = nullptr;
     int64_t work_stride = 0;
     std::vector<void *> owned;
+    // the staging copy of the inputs (kept while small: stage_general), the result region of the
+    // arena ([info | logml_base | logml_full | mu | sigma], offsets from info) and whether logdet /
+    // info still hold the zeros they were staged with
+    std::vector<unsigned char> h_in, h_out;
+    size_t out_off[5] = {}, out_bytes = 0;
+    bool zeroed = false, copy_in_flight = false;
     // the spec the job was staged under: a later ngp_set_spec does not reach a staged job
     ngp_spec spec{};
     // lattice jobs: items whose reduced program is a chain of more than one instruction / the other
@@ -654,6 +660,10 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
     }
 }
 
+// stage_general keeps a staging buffer up to this size with the job instead of waiting for the copy;
+// ngp_job_fetch brings a result region up to FETCH_PACKED_BYTES back in one copy
+constexpr size_t STAGE_KEEP_BYTES = (size_t)4 << 20, FETCH_PACKED_BYTES = (size_t)1 << 20;
+
 template <class T> ngp_status job_alloc(ngp_job *j, T **p, size_t count) {
     void *v = nullptr;
     ngp_status st = j->ctx->alloc(&v, count * sizeof(T));
@@ -735,70 +745,106 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
         return s;
     };
     const int ny = g.y_shared ? 1 : P;
-    // host-side assembly of the small inputs
-    std::vector<double> h_taux((size_t)std::max(g.da + m, 1));
-    for (int a = 0; a < g.tail; ++a) h_taux[(size_t)a] = t[g.n0 + a];
-    for (int a = 0; a < d; ++a) h_taux[(size_t)(g.tail + a)] = t_add[a];
-    for (int i = 0; i < m; ++i) h_taux[(size_t)(g.da + i)] = t_new[i];
-    std::vector<double> h_y0((size_t)std::max(ny * g.n0, 1));
-    for (int b = 0; b < ny; ++b)
-        for (int i = 0; i < g.n0; ++i) h_y0[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
-    std::vector<double> h_ya((size_t)std::max((int64_t)ny * D * g.da, (int64_t)1));
-    for (int b = 0; b < ny; ++b)
-        for (int s = 0; s < D; ++s) {
-            double *dst = &h_ya[((size_t)b * D + s) * g.da];
-            for (int a = 0; a < g.tail; ++a) dst[a] = y[(int64_t)b * ldy + g.n0 + a];
-            for (int a = 0; a < d; ++a)
-                dst[g.tail + a] = y_add[(int64_t)b * ld_yadd_item + (int64_t)s * d + a];
-        }
-    if ((st = job_alloc(j, &j->progs, (size_t)P))) return fail(st);
-    if ((st = job_alloc(j, &j->t0, (size_t)std::max(g.n0, 1)))) return fail(st);
-    if ((st = job_alloc(j, &j->taux, h_taux.size()))) return fail(st);
-    if ((st = job_alloc(j, &j->y0, h_y0.size()))) return fail(st);
-    if ((st = job_alloc(j, &j->ya, h_ya.size()))) return fail(st);
-    if (g.lattice && (st = job_alloc(j, &j->qpts, (size_t)g.npts))) return fail(st);
-    if ((st = job_alloc(j, &j->logdet, (size_t)P))) return fail(st);
-    if ((st = job_alloc(j, &j->info, (size_t)P))) return fail(st);
-    if ((st = job_alloc(j, &j->G, (size_t)P * g.naux * g.naux))) return fail(st);
-    j->work_stride = (int64_t)g.da * g.da + (int64_t)m * g.da + g.da + 8;
-    if ((st = job_alloc(j, &j->work, (size_t)P * j->work_stride))) return fail(st);
-    if ((st = job_alloc(j, &j->zbuf, (size_t)std::max((int64_t)P * D * g.da, (int64_t)1))))
-        return fail(st);
-    if ((st = job_alloc(j, &j->logml_base, (size_t)P))) return fail(st);
-    if ((st = job_alloc(j, &j->logml_full, (size_t)P * D))) return fail(st);
-    if (m > 0) {
-        if ((st = job_alloc(j, &j->mu, (size_t)P * D * m))) return fail(st);
-        if ((st = job_alloc(j, &j->sigma, (size_t)P * m * m))) return fail(st);
-    }
-    hipStream_t s = c->stream;
-#define CPY(dst, src, cnt, T)                                                                  \
-    do {                                                                                       \
-        if ((cnt) > 0 && hipMemcpyAsync(dst, src, (size_t)(cnt) * sizeof(T),                  \
-                                        hipMemcpyHostToDevice, s) != hipSuccess)               \
-            return fail(NGP_ERR_STATE);                                                        \
-    } while (0)
-    CPY(j->progs, hp.data(), P, DevProgram);
-    CPY(j->t0, t, g.n0, double);
-    CPY(j->taux, h_taux.data(), g.da + m, double);
-    CPY(j->y0, h_y0.data(), ny * g.n0, double);
-    CPY(j->ya, h_ya.data(), (int64_t)ny * D * g.da, double);
-    if (g.lattice) CPY(j->qpts, h_q.data(), g.npts, int32_t);
-    if (g.lattice && g.n0 > 0) {
+    if (g.lattice && g.n0 > 0)
         for (int i = 0; i < P; ++i)
             (hp[(size_t)i].n_rops == 1 && hp[(size_t)i].rops[0] == OP_TABLE
                  ? j->fill_single
                  : hp[(size_t)i].rchain ? j->fill_chain : j->fill_other)
                 .push_back(i);
-        if ((st = job_alloc(j, &j->fill_chain_d, std::max<size_t>(j->fill_chain.size(), 1))) ||
-            (st = job_alloc(j, &j->fill_other_d, std::max<size_t>(j->fill_other.size(), 1))) ||
-            (st = job_alloc(j, &j->fill_single_d, std::max<size_t>(j->fill_single.size(), 1))))
-            return fail(st);
-        CPY(j->fill_single_d, j->fill_single.data(), j->fill_single.size(), int32_t);
-        CPY(j->fill_chain_d, j->fill_chain.data(), j->fill_chain.size(), int32_t);
-        CPY(j->fill_other_d, j->fill_other.data(), j->fill_other.size(), int32_t);
+    // ONE device arena for everything that crosses the bus, inputs first, outputs last:
+    //   [programs | t0 | taux | y0 | ya | lattice indices | fill lists | logdet | info |
+    //    logml_base | logml_full | mu | sigma]
+    // The inputs go up in ONE copy (logdet and info arrive as the zeros the first run expects) and
+    // a small job's results come back in one (ngp_job_fetch): the 24- and 64-particle calls of a
+    // fit on a short series are chains of dependent launches a few microseconds long, and every
+    // separate copy or memset was one more link (ten copies and two memsets before).
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al(std::max<size_t>(bytes, 8)); return o; };
+    const size_t n_t0 = (size_t)std::max(g.n0, 1), n_taux = (size_t)std::max(g.da + m, 1),
+                 n_y0 = (size_t)std::max(ny * g.n0, 1),
+                 n_ya = (size_t)std::max((int64_t)ny * D * g.da, (int64_t)1);
+    const size_t o_progs = take(sizeof(DevProgram) * (size_t)P), o_t0 = take(8 * n_t0),
+                 o_taux = take(8 * n_taux), o_y0 = take(8 * n_y0), o_ya = take(8 * n_ya),
+                 o_q = take(g.lattice ? 4 * (size_t)g.npts : 0),
+                 o_fs = take(4 * j->fill_single.size()), o_fc = take(4 * j->fill_chain.size()),
+                 o_fo = take(4 * j->fill_other.size()), o_logdet = take(8 * (size_t)P),
+                 o_info = take(4 * (size_t)P);
+    const size_t in_bytes = off;
+    const size_t o_lb = take(8 * (size_t)P), o_lf = take(8 * (size_t)P * D),
+                 o_mu = take(m > 0 ? 8 * (size_t)P * D * m : 0),
+                 o_sigma = take(m > 0 ? 8 * (size_t)P * m * m : 0);
+    j->h_in.assign(in_bytes, 0);
+    {
+        unsigned char *h = j->h_in.data();
+        std::memcpy(h + o_progs, hp.data(), sizeof(DevProgram) * (size_t)P);
+        if (g.n0 > 0) std::memcpy(h + o_t0, t, 8 * (size_t)g.n0);
+        double *h_taux = (double *)(h + o_taux), *h_y0 = (double *)(h + o_y0),
+               *h_ya = (double *)(h + o_ya);
+        for (int a = 0; a < g.tail; ++a) h_taux[a] = t[g.n0 + a];
+        for (int a = 0; a < d; ++a) h_taux[g.tail + a] = t_add[a];
+        for (int i = 0; i < m; ++i) h_taux[g.da + i] = t_new[i];
+        for (int b = 0; b < ny; ++b)
+            for (int i = 0; i < g.n0; ++i) h_y0[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
+        for (int b = 0; b < ny; ++b)
+            for (int sc = 0; sc < D; ++sc) {
+                double *dst = h_ya + ((size_t)b * D + sc) * g.da;
+                for (int a = 0; a < g.tail; ++a) dst[a] = y[(int64_t)b * ldy + g.n0 + a];
+                for (int a = 0; a < d; ++a)
+                    dst[g.tail + a] = y_add[(int64_t)b * ld_yadd_item + (int64_t)sc * d + a];
+            }
+        if (g.lattice) std::memcpy(h + o_q, h_q.data(), 4 * (size_t)g.npts);
+        if (!j->fill_single.empty())
+            std::memcpy(h + o_fs, j->fill_single.data(), 4 * j->fill_single.size());
+        if (!j->fill_chain.empty())
+            std::memcpy(h + o_fc, j->fill_chain.data(), 4 * j->fill_chain.size());
+        if (!j->fill_other.empty())
+            std::memcpy(h + o_fo, j->fill_other.data(), 4 * j->fill_other.size());
     }
-#undef CPY
-    if (hipStreamSynchronize(s) != hipSuccess) return fail(NGP_ERR_STATE);
+    unsigned char *io = nullptr;
+    if ((st = job_alloc(j, &io, off))) return fail(st);
+    j->progs = (DevProgram *)(io + o_progs);
+    j->t0 = (double *)(io + o_t0);
+    j->taux = (double *)(io + o_taux);
+    j->y0 = (double *)(io + o_y0);
+    j->ya = (double *)(io + o_ya);
+    if (g.lattice) j->qpts = (int32_t *)(io + o_q);
+    if (g.lattice && g.n0 > 0) {
+        j->fill_single_d = (int32_t *)(io + o_fs);
+        j->fill_chain_d = (int32_t *)(io + o_fc);
+        j->fill_other_d = (int32_t *)(io + o_fo);
+    }
+    j->logdet = (double *)(io + o_logdet);
+    j->info = (int32_t *)(io + o_info);
+    j->logml_base = (double *)(io + o_lb);
+    j->logml_full = (double *)(io + o_lf);
+    if (m > 0) {
+        j->mu = (double *)(io + o_mu);
+        j->sigma = (double *)(io + o_sigma);
+    }
+    j->out_off[0] = 0;                     // offsets inside the result region, which starts at info
+    j->out_off[1] = o_lb - o_info;
+    j->out_off[2] = o_lf - o_info;
+    j->out_off[3] = o_mu - o_info;
+    j->out_off[4] = o_sigma - o_info;
+    j->out_bytes = off - o_info;
+    if ((st = job_alloc(j, &j->G, (size_t)P * g.naux * g.naux))) return fail(st);
+    j->work_stride = (int64_t)g.da * g.da + (int64_t)m * g.da + g.da + 8;
+    if ((st = job_alloc(j, &j->work, (size_t)P * j->work_stride))) return fail(st);
+    if ((st = job_alloc(j, &j->zbuf, (size_t)std::max((int64_t)P * D * g.da, (int64_t)1))))
+        return fail(st);
+    hipStream_t s = c->stream;
+    if (hipMemcpyAsync(io, j->h_in.data(), in_bytes, hipMemcpyHostToDevice, s) != hipSuccess)
+        return fail(NGP_ERR_STATE);
+    j->zeroed = true;
+    j->copy_in_flight = true;
+    // a small staging buffer stays with the job (no wait here: the run is queued right behind the
+    // copy); a large one is given back once the copy has left it
+    if (in_bytes > STAGE_KEEP_BYTES) {
+        if (hipStreamSynchronize(s) != hipSuccess) return fail(NGP_ERR_STATE);
+        std::vector<unsigned char>().swap(j->h_in);
+        j->copy_in_flight = false;
+    }
     *out = j;
     return NGP_OK;
 }
@@ -905,8 +951,11 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     hipStream_t s = c->stream;
     const DevSpec sp = dev_spec(j->spec);
     EventTimer tm(c->profiling, s);
-    HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)g.B, s));
-    HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
+    if (!j->zeroed) {   // a re-run: the first one finds the zeros the staging copy brought
+        HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)g.B, s));
+        HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
+    }
+    j->zeroed = false;
     // mixed precision needs at least one fat step (two block columns); shorter series run fp64, and
     // so do series of more than 129 block columns (n > 8,319): a fat step classifies its k-tiles
     // in two 64-bit masks
@@ -1107,6 +1156,19 @@ extern "C" ngp_status ngp_job_fetch(ngp_job *j, double *logml_base, double *logm
     HIPCHK(hipSetDevice(c->device));
     const JobGeom &g = j->g;
     hipStream_t s = c->stream;
+    if (j->out_bytes <= FETCH_PACKED_BYTES) {   // small results: one copy of the whole region
+        j->h_out.resize(j->out_bytes);
+        HIPCHK(hipMemcpyAsync(j->h_out.data(), j->info, j->out_bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        j->copy_in_flight = false;
+        const unsigned char *h = j->h_out.data();
+        if (info) std::memcpy(info, h + j->out_off[0], 4 * (size_t)g.B);
+        if (logml_base) std::memcpy(logml_base, h + j->out_off[1], 8 * (size_t)g.B);
+        if (logml_full) std::memcpy(logml_full, h + j->out_off[2], 8 * (size_t)g.B * g.D);
+        if (mu && g.m > 0) std::memcpy(mu, h + j->out_off[3], 8 * (size_t)g.B * g.D * g.m);
+        if (sigma && g.m > 0) std::memcpy(sigma, h + j->out_off[4], 8 * (size_t)g.B * g.m * g.m);
+        return NGP_OK;
+    }
     if (logml_base)
         HIPCHK(hipMemcpyAsync(logml_base, j->logml_base, sizeof(double) * (size_t)g.B,
                               hipMemcpyDeviceToHost, s));
@@ -1123,6 +1185,7 @@ extern "C" ngp_status ngp_job_fetch(ngp_job *j, double *logml_base, double *logm
         HIPCHK(hipMemcpyAsync(info, j->info, sizeof(int32_t) * (size_t)g.B, hipMemcpyDeviceToHost,
                               s));
     HIPCHK(hipStreamSynchronize(s));
+    j->copy_in_flight = false;
     return NGP_OK;
 }
 
@@ -1130,6 +1193,9 @@ extern "C" void ngp_job_destroy(ngp_job *j) {
     if (!j) return;
     {
         std::lock_guard<std::mutex> lk(j->ctx->mu);
+        // staged but never fetched: the staging copy may still be reading j->h_in
+        if (j->copy_in_flight && hipSetDevice(j->ctx->device) == hipSuccess)
+            (void)hipStreamSynchronize(j->ctx->stream);
         for (void *p : j->owned) j->ctx->release(p);
     }
     delete j;
@@ -1519,8 +1585,6 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     g.npts = g.n0;
     g.maxstat = std::max(maxstat, 1);
     g.maxcp = std::max(maxcp, 1);
-    std::vector<double> h_t((size_t)g.n0, t[n - 1]);
-    for (int i = 0; i < n; ++i) h_t[(size_t)i] = t[i];
     std::vector<int32_t> h_q;
     {
         std::vector<double> real(t, t + n);
@@ -1534,16 +1598,33 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         }
     }
     const int ny = g.y_shared ? 1 : B;
-    std::vector<double> h_y((size_t)ny * g.n0, 0.0);
-    for (int b = 0; b < ny; ++b)
-        for (int i = 0; i < n; ++i) h_y[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
+    const int GP = NGP_MAX_PARAMS + 1;
+    // ONE device arena for everything that crosses the bus: [programs | t | y | lattice indices |
+    // info | logdet | gradient | logml].  The front part goes up in one copy (info and logdet
+    // arrive as the zeros the factorisation expects), the tail comes back in one: a 24-particle
+    // call of a fit on a short series is a chain of dependent launches a few microseconds long,
+    // and each separate copy or memset was one more of them.
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_t = al(sizeof(DevProgram) * (size_t)B), o_y = o_t + al(8 * (size_t)g.n0),
+                 o_q = o_y + al(8 * (size_t)ny * g.n0),
+                 o_info = o_q + (g.lattice ? al(4 * (size_t)g.n0) : 0),
+                 o_logdet = o_info + al(4 * (size_t)B), o_grad = o_logdet + al(8 * (size_t)B),
+                 o_logml = o_grad + al(8 * (size_t)B * GP), io_bytes = o_logml + al(8 * (size_t)B);
+    std::vector<unsigned char> h_in(o_grad, 0), h_out(io_bytes - o_info);
+    std::memcpy(h_in.data(), hp.data(), sizeof(DevProgram) * (size_t)B);
+    {
+        double *ht = (double *)(h_in.data() + o_t), *hy = (double *)(h_in.data() + o_y);
+        for (int i = 0; i < g.n0; ++i) ht[i] = t[std::min(i, n - 1)];
+        for (int b = 0; b < ny; ++b)
+            for (int i = 0; i < n; ++i) hy[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
+        if (g.lattice) std::memcpy(h_in.data() + o_q, h_q.data(), 4 * (size_t)g.n0);
+    }
 
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const DevSpec sp = dev_spec(c->spec);
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
-    const int GP = NGP_MAX_PARAMS + 1;
     std::vector<void *> owned;
     auto freeall = [&] { for (void *q : owned) c->release(q); };
     auto dalloc = [&](void **q, size_t bytes) -> ngp_status {
@@ -1559,18 +1640,13 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     if ((size_t)B * item_bytes > c->mem_cap) c->refresh_mem_cap();   // large job: today's figure
     int Bc = (int)std::min<size_t>(std::min<size_t>((size_t)B, MAX_CHUNK_ITEMS),
                                    std::max<size_t>(1, c->mem_cap / item_bytes));
-    void *d_prog, *d_t, *d_y, *d_q = nullptr, *d_logdet, *d_info, *d_L, *d_dinv, *d_tab = nullptr,
-         *d_sig = nullptr, *d_dtab = nullptr, *d_kinv, *d_alpha, *d_quad, *d_part, *d_grad, *d_logml,
-         *d_items;
+    void *d_io, *d_L, *d_dinv, *d_tab = nullptr, *d_sig = nullptr, *d_dtab = nullptr, *d_kinv,
+         *d_alpha, *d_quad, *d_part, *d_items;
     std::vector<int32_t> h_items((size_t)B);   // alive until the stream is synchronised below
     ngp_status st;
     // the chunk is halved when the device cannot hold it after all (other handles, rounding)
     for (;; Bc = (Bc + 1) / 2) {
-        if (!((st = dalloc(&d_prog, sizeof(DevProgram) * (size_t)B)) ||
-              (st = dalloc(&d_t, 8 * (size_t)g.n0)) || (st = dalloc(&d_y, 8 * h_y.size())) ||
-              (g.lattice && (st = dalloc(&d_q, 4 * (size_t)g.n0))) ||
-              (st = dalloc(&d_logdet, 8 * (size_t)B)) || (st = dalloc(&d_info, 4 * (size_t)B)) ||
-              (st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
+        if (!((st = dalloc(&d_io, io_bytes)) || (st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
               (st = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
               (g.lattice && ((st = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
                              (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)) ||
@@ -1582,21 +1658,18 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
               (st = dalloc(&d_part,
                            8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc), 4096) *
                                GP)) ||
-              (st = dalloc(&d_grad, 8 * (size_t)B * GP)) || (st = dalloc(&d_logml, 8 * (size_t)B)) ||
               (st = dalloc(&d_items, 4 * (size_t)B))))
             break;
         freeall();
         owned.clear();
         if (st != NGP_ERR_TOO_LARGE || Bc <= 1) return st;
     }
-    hipError_t e = hipMemcpyAsync(d_prog, hp.data(), sizeof(DevProgram) * (size_t)B,
-                                  hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_t, h_t.data(), 8 * h_t.size(), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_y, h_y.data(), 8 * h_y.size(), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && g.lattice)
-        e = hipMemcpyAsync(d_q, h_q.data(), 4 * (size_t)g.n0, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_logdet, 0, 8 * (size_t)B, s);
-    if (e == hipSuccess) e = hipMemsetAsync(d_info, 0, 4 * (size_t)B, s);
+    unsigned char *const io = (unsigned char *)d_io;
+    void *const d_prog = io, *const d_t = io + o_t, *const d_y = io + o_y,
+                *const d_q = g.lattice ? io + o_q : nullptr, *const d_info = io + o_info,
+                *const d_logdet = io + o_logdet, *const d_grad = io + o_grad,
+                *const d_logml = io + o_logml;
+    hipError_t e = hipMemcpyAsync(d_io, h_in.data(), h_in.size(), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) { freeall(); return (ngp_status)e; }
     EventTimer tm(c->profiling, s);
     for (int b0 = 0; b0 < B; b0 += Bc) {
@@ -1627,8 +1700,12 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         });
         // the chunk's items sorted by tree size: every size class runs on the contraction kernel
         // sized for it
+        // (small launches — the 24- or 64-particle calls of a fit on short series — stay ONE launch
+        // sized by the largest tree: up to five dependent launches of a few microseconds each cost
+        // more there than the occupancy of the smaller instantiations gains)
+        const bool by_size = g.lattice && (long)ntri * bc > 4096;
         int32_t counts[GRAD_BUCKETS] = {};
-        {
+        if (by_size) {
             for (int i = 0; i < bc; ++i) ++counts[grad_bucket(kernels[b0 + i].n_ops)];
             int32_t pos[GRAD_BUCKETS], acc = 0;
             for (int k = 0; k < GRAD_BUCKETS; ++k) { pos[k] = acc; acc += counts[k]; }
@@ -1647,20 +1724,19 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
             launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
                                  (const double *)d_quad, (double *)d_part,
                                  (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc,
-                                 sp, s, g.lattice ? (const int32_t *)d_items + b0 : nullptr, counts);
+                                 sp, s, by_size ? (const int32_t *)d_items + b0 : nullptr, counts);
         });
     }
-    std::vector<double> h_grad((size_t)B * GP), h_lm((size_t)B);
-    std::vector<int32_t> h_info((size_t)B);
-    e = hipMemcpyAsync(h_grad.data(), d_grad, 8 * h_grad.size(), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_lm.data(), d_logml, 8 * (size_t)B, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(h_info.data(), d_info, 4 * (size_t)B, hipMemcpyDeviceToHost, s);
+    e = hipMemcpyAsync(h_out.data(), d_info, h_out.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();
     tm.resolve(c->prof);
     freeall();
     if (e != hipSuccess) return (ngp_status)e;
     // device parameter order -> caller's order; d/d noise last
+    const int32_t *h_info = (const int32_t *)h_out.data();
+    const double *h_grad = (const double *)(h_out.data() + (o_grad - o_info)),
+                 *h_lm = (const double *)(h_out.data() + (o_logml - o_info));
     size_t off = 0;
     for (int i = 0; i < B; ++i) {
         const int np = kernels[i].n_params;

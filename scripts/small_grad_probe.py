@@ -8,7 +8,7 @@ from nowcastautogp_amd._abi import KernelArray, as_f64, dptr, iptr
 from nowcastautogp_amd.synthetic import make_workload
 ctx = _lib.Context(0)
 L = _lib.load()
-for n, P in ((150, 24), (150, 64), (300, 64)):
+for n, P in ((208, 24), (150, 24), (150, 64), (300, 64)):
     w = make_workload("C3", n=n, P=P, D=4)
     fn = lambda: ctx.logml_grad_batch(w.programs, w.t, w.y)
     for _ in range(5): fn()
