@@ -252,6 +252,32 @@ struct ngp_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;          // diag-ahead tiles run beside the main schedule
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // extra lanes: small chunks of long series are swept as several sub-chunks side by side
+    // (factor_chunk); made on first use
+    static constexpr int MAX_LANES = 2;
+    hipStream_t lane_main[MAX_LANES] = {}, lane_side[MAX_LANES] = {};
+    hipEvent_t lane_fork[MAX_LANES] = {}, lane_join[MAX_LANES] = {}, lane_done[MAX_LANES] = {};
+    hipEvent_t ev_lane_go = nullptr;
+    int lanes_made = 1;   // lane 0 is (stream, side, ev_fork, ev_join)
+    bool make_lanes(int n) {
+        if (!ev_lane_go && hipEventCreateWithFlags(&ev_lane_go, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            ev_lane_go = nullptr;
+            return false;
+        }
+        for (; lanes_made < n; ++lanes_made) {
+            const int i = lanes_made;
+            if (hipStreamCreateWithFlags(&lane_main[i], hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&lane_side[i], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&lane_fork[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&lane_join[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&lane_done[i], hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+        }
+        return true;
+    }
     ngp_spec spec{};
     std::mutex mu;
     bool profiling = false;
@@ -428,6 +454,13 @@ extern "C" void ngp_ctx_destroy(ngp_ctx *c) {
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (int i = 1; i < ngp_ctx::MAX_LANES; ++i) {
+        if (c->lane_main[i]) { (void)hipStreamSynchronize(c->lane_main[i]); (void)hipStreamDestroy(c->lane_main[i]); }
+        if (c->lane_side[i]) { (void)hipStreamSynchronize(c->lane_side[i]); (void)hipStreamDestroy(c->lane_side[i]); }
+        for (hipEvent_t e : {c->lane_fork[i], c->lane_join[i], c->lane_done[i]})
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (c->ev_lane_go) (void)hipEventDestroy(c->ev_lane_go);
     delete c;
 }
 
@@ -569,17 +602,62 @@ constexpr size_t MAX_CHUNK_ITEMS = 65535;   // gridDim.y
 inline bool item_too_large(int64_t item_stride) { return item_stride * 8 > (int64_t)0x7fffffff; }
 constexpr int MIXED_REORDER = 16;
 constexpr int AHEAD_EARLY_MAX_ITEMS = 512;
+// Two lanes pay from n ~ 1500 and 64 items on (measured, 64 items: n = 2048 logml 6.78 -> 6.57 ms,
+// logml + gradient 17.07 -> 16.41; n = 1024: 2.00 -> 2.20 and 4.13 -> 4.21, so not there); three and
+// four lanes were slower everywhere (more streams than hardware queues).
+constexpr int TWO_LANE_MIN_ITEMS = 64, TWO_LANE_MIN_NB = 24;
 void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int bc, EventTimer &tm,
                   size_t dinv_step = 0, const DevSpec *sp = nullptr, int32_t *order_buf = nullptr,
-                  unsigned *order_prev = nullptr) {
+                  unsigned *order_prev = nullptr, bool half = false) {
     ChunkPtrs p0 = p_in;
     const bool mixed = sp != nullptr && p0.L32 != nullptr;
     hipStream_t s = ln.main;
     // small chunks of long series: room for the split-k fat steps (chol_col_glds_kernel<.., SPLITK>);
     // the buffer stays with the context
-    if (bc <= AHEAD_EARLY_MAX_ITEMS && !mixed && !g.aux_identity && g.nb0 >= 8 &&
+    if (!half && bc <= AHEAD_EARLY_MAX_ITEMS && !mixed && !g.aux_identity && g.nb0 >= 8 &&
         ln.ctx->splitk_reserve(bc) == NGP_OK)
         p0.splitk_part = ln.ctx->splitk_part;
+    // Small chunks of long series (the 64-particle calls of a fit) are swept as two half-chunks side
+    // by side, each on its own pair of streams (lanes).  A launch of such a chunk rarely fills the chip or
+    // fills it one and a fraction times (64 items at n = 2048: 576 workgroups on 512 slots at
+    // column 14 — two rounds for the price of 1.1), and chol_diag / the thin step leave it almost
+    // empty: the other half's fat step runs in those gaps.  Every item's arithmetic is what it
+    // would be in a chunk of its half's size.
+    const int nl = ngp_ctx::MAX_LANES;
+    if (!half && !mixed && nl >= 2 && bc >= TWO_LANE_MIN_ITEMS && bc <= AHEAD_EARLY_MAX_ITEMS &&
+        g.nb0 >= TWO_LANE_MIN_NB && ln.main == ln.ctx->stream && ln.ctx->make_lanes(nl)) {
+        ngp_ctx *c = ln.ctx;
+        (void)hipEventRecord(c->ev_lane_go, s);
+        std::vector<EventTimer> tms;
+        tms.reserve((size_t)nl);
+        int h0 = 0;
+        for (int i = 0; i < nl; ++i) {
+            const int h1 = (int)((long)bc * (i + 1) / nl);
+            ChunkPtrs pi = p0;
+            pi.L += (size_t)h0 * g.item_stride;
+            pi.dinv += (size_t)h0 * NB * NB;
+            pi.progs += h0;
+            pi.logdet += h0;
+            pi.info += h0;
+            if (pi.splitk_part) pi.splitk_part += (size_t)h0 * SPLITK_SLOTS * 4 * 64 * 64;
+            if (i == 0) {
+                factor_chunk(ln, g, pi, h1 - h0, tm, dinv_step, sp, order_buf, order_prev, true);
+            } else {
+                const Lane li{c->lane_main[i], c->lane_side[i], c->lane_fork[i], c->lane_join[i], c};
+                tms.emplace_back(tm.on, li.main);
+                (void)hipStreamWaitEvent(li.main, c->ev_lane_go, 0);
+                factor_chunk(li, g, pi, h1 - h0, tms.back(), dinv_step, sp, order_buf, order_prev, true);
+                (void)hipEventRecord(c->lane_done[i], li.main);
+            }
+            h0 = h1;
+        }
+        for (int i = 1; i < nl; ++i) (void)hipStreamWaitEvent(s, c->lane_done[i], 0);
+        for (auto &t : tms) {
+            tm.recs.insert(tm.recs.end(), t.recs.begin(), t.recs.end());
+            t.recs.clear();
+        }
+        return;
+    }
     const double nrows_aux = (double)g.naux;
     bool ahead_pending = false;
     for (int jj = 0; jj < g.nb0; ++jj) {

@@ -8,11 +8,14 @@ ge.build()
 from nowcastautogp_amd import _lib
 from nowcastautogp_amd.synthetic import make_workload
 ctx = _lib.Context(0)
-for n, P in ((208, 24), (208, 64), (512, 24)):
+CASES = ((208, 24), (208, 64), (512, 24))
+if len(sys.argv) > 1:   # e.g.  2048x64 1024x64 512x64
+    CASES = tuple(tuple(int(v) for v in a.split("x")) for a in sys.argv[1:])
+for n, P in CASES:
     w = make_workload("C3", n=n, P=P)
     for _ in range(5):
         ctx.logml_grad_batch(w.programs, w.t, w.y)
-    N = 300
+    N = 300 if n <= 512 else 40
     t0 = time.perf_counter()
     for _ in range(N):
         ctx.logml_grad_batch(w.programs, w.t, w.y)
