@@ -472,6 +472,44 @@ def test_headline_size_2048_gradient_and_resident_factor(ctx):
     f.close()
 
 
+def test_two_lane_sweep_of_small_chunks_is_the_sweep_of_its_halves(ctx):
+    """Chunks of 64..512 items of a long series (n0 >= 1536) are swept as two half-chunks side by
+    side on two stream pairs (factor_chunk).  Every item's arithmetic must be what it is in a
+    chunk of its half's size: a 65-item call equals, bit for bit, the calls of its first 32 and
+    last 33 items (each below the two-lane threshold: one lane) — logml, gradient, the predictive
+    and the resident factor's queries; and a sample agrees with the oracle."""
+    w = make_workload("C3", n=1537 + 22, P=65, D=3)          # ragged tail: n0 = 1536, 23 aux rows
+    progs = w.programs
+    h = len(progs) // 2
+    lm, info = ctx.logml_batch(progs, w.t, w.y)
+    la, _ = ctx.logml_batch(progs[:h], w.t, w.y)
+    lb, _ = ctx.logml_batch(progs[h:], w.t, w.y)
+    assert not info.any()
+    assert np.array_equal(lm, np.concatenate([la, lb]))
+    glm, grads, ginfo = ctx.logml_grad_batch(progs, w.t, w.y)
+    ga = ctx.logml_grad_batch(progs[:h], w.t, w.y)
+    gb = ctx.logml_grad_batch(progs[h:], w.t, w.y)
+    assert not ginfo.any()
+    assert np.array_equal(glm, np.concatenate([ga[0], gb[0]]))
+    for k in range(len(progs)):
+        assert np.array_equal(grads[k], (ga[1] + gb[1])[k]), k
+    got = ctx.nowcast_batch(progs, w.t, w.y, w.t_add, w.y_add, w.t_new)
+    ra = ctx.nowcast_batch(progs[:h], w.t, w.y, w.t_add, w.y_add, w.t_new)
+    rb = ctx.nowcast_batch(progs[h:], w.t, w.y, w.t_add, w.y_add, w.t_new)
+    for key in ("logml_base", "logml_full", "mu", "sigma"):
+        assert np.array_equal(got[key], np.concatenate([ra[key], rb[key]])), key
+    f = ctx.factor(progs, w.t, w.y)
+    q = f.nowcast(w.t_add, w.y_add, w.t_new)
+    f.close()
+    for key in ("logml_base", "logml_full", "mu", "sigma"):
+        assert nerr(q[key], got[key]) < 1e-9, key
+    for i in (0, h - 1, h, len(progs) - 1):
+        ref, oi = oracle_np.logml(progs[i], w.t, w.y)
+        assert oi == 0
+        cond = np.linalg.cond(oracle_np.cov(progs[i], w.t, w.t, True))
+        check("test_two_lane_sweep:logml", lm[i], ref, TOL_LOGML, cond, ctx=(i,))
+
+
 def test_gradient_matches_oracle_on_golden(ctx, golden):
     """d logml / d(theta, noise) = 1/2 tr((aa' - K^-1) dK): GPU (identity aux rows -> K^-1 by MFMA
     Gram, reverse-mode tree sweep) vs the C oracle's forward-mode analytic gradient.  Stated
