@@ -486,7 +486,14 @@ def _item_y(ys, owner):
     shared vector for a single model, else one row per item (``ldy = n`` in include/ngp.h)."""
     if len(ys) == 1:
         return ys[0]
-    return np.stack(ys)[np.asarray(owner, dtype=np.int64)]
+    own = np.asarray(owner, dtype=np.int64)
+    rows = np.stack(ys)
+    # the usual case — every model's items together, model after model, equally many each — is a
+    # plain repeat (0.1 s for the 210 MB of 64 x 200 items; the row gather takes five times that)
+    per = own.size // len(ys) if len(ys) else 0
+    if per * len(ys) == own.size and np.array_equal(own, np.repeat(np.arange(len(ys)), per)):
+        return np.repeat(rows, per, axis=0)
+    return rows[own]
 
 
 _KIND_CODE_CACHE = {}
