@@ -1779,7 +1779,7 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         const double n3 = (double)g.n0 * g.n0 * g.n0;
         tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
             launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
-                             (double *)d_quad, bc, s);
+                             (double *)d_quad, bc, s, c->side, c->ev_fork, c->ev_join);
         });
         // the chunk's items sorted by tree size: every size class runs on the contraction kernel
         // sized for it
@@ -1807,7 +1807,8 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
             launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
                                  (const double *)d_quad, (double *)d_part,
                                  (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc,
-                                 sp, s, by_size ? (const int32_t *)d_items + b0 : nullptr, counts);
+                                 sp, s, by_size ? (const int32_t *)d_items + b0 : nullptr, counts,
+                                 c->side, c->ev_fork, c->ev_join);
         });
     }
     e = hipMemcpyAsync(h_out.data(), d_info, h_out.size(), hipMemcpyDeviceToHost, s);

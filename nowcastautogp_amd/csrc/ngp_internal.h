@@ -165,8 +165,10 @@ void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipS
 constexpr int NGP_MIXED_ORDER_MAX = 8192;   // items mixed_order_kernel ranks in LDS (32 KiB)
 bool launch_mixed_order(const ChunkPtrs &p, unsigned *prev, int32_t *order, int Bc, hipStream_t s);
 void launch_aux_update(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipStream_t s);
+// side / fork / join: when given, alpha is computed beside K^-1 on the side stream
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
-                      int Bc, hipStream_t s);
+                      int Bc, hipStream_t s, hipStream_t side = nullptr, hipEvent_t fork = nullptr,
+                      hipEvent_t join = nullptr);
 // items / bucket_counts: the chunk's items (chunk-local indices) sorted by tree size into
 // GRAD_BUCKETS groups — at most 1, 2, 4, 8, 16 leaves, larger — and the size of every group;
 // null: one launch for the whole chunk, sized by g.maxops
@@ -177,7 +179,9 @@ inline int grad_bucket(int n_ops) {
 void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
                           const double *alpha, const double *quad, double *partials, double *grad,
                           double *logml, int Bc, const DevSpec &sp, hipStream_t s,
-                          const int32_t *items = nullptr, const int32_t *bucket_counts = nullptr);
+                          const int32_t *items = nullptr, const int32_t *bucket_counts = nullptr,
+                          hipStream_t side = nullptr, hipEvent_t fork = nullptr,
+                          hipEvent_t join = nullptr);
 // workgroups per 64x64 tile of the gradient contraction: small launches are cut finer
 inline int grad_contract_split(long ntri, long Bc) {
     return ntri * Bc <= 1024 ? 4 : (ntri * Bc <= 2048 ? 2 : 1);

@@ -2246,9 +2246,19 @@ __global__ __launch_bounds__(128) void grad_reduce_kernel(JobGeom g, const DevPr
     const int item = blockIdx.x, pidx = threadIdx.x;
     const int np = progs[item].n_params;
     if (pidx <= np) {
+        // t ascending, as ever (the sum's bits do not depend on the launch); sixteen loads in
+        // flight at a time — one dependent load per addition made this 0.2 ms of a 64-particle call
+        const double *src = partials + (long)item * ntri * (NGP_MAX_PARAMS + 1) + pidx;
         double s = 0.0;
-        for (int t = 0; t < ntri; ++t)
-            s += partials[((long)item * ntri + t) * (NGP_MAX_PARAMS + 1) + pidx];
+        int t = 0;
+        for (; t + 16 <= ntri; t += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = src[(long)(t + u) * (NGP_MAX_PARAMS + 1)];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += v[u];
+        }
+        for (; t < ntri; ++t) s += src[(long)t * (NGP_MAX_PARAMS + 1)];
         grad[(long)item * (NGP_MAX_PARAMS + 1) + pidx] = s;
     }
     if (pidx == 0)
@@ -2584,7 +2594,17 @@ void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipS
 }
 
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
-                      int Bc, hipStream_t s) {
+                      int Bc, hipStream_t s, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+    // alpha = W_I z reads every row of W once (18.5 MB per item at n = 2048: HBM-bound) and does not
+    // depend on K^-1 (MFMA-bound): it runs beside it on the side stream
+    const bool beside = side && fork && join;
+    if (beside) {
+        (void)hipEventRecord(fork, s);
+        (void)hipStreamWaitEvent(side, fork, 0);
+        hipLaunchKernelGGL(grad_alpha_kernel, dim3((g.n0 + 1 + 3) / 4, Bc), dim3(256), 0, side, g, L,
+                           alpha, quad);
+        (void)hipEventRecord(join, side);
+    }
     const int npairs = g.nb0 * (g.nb0 + 1) / 2;
     if (g.nb0 >= 8) {   // long series: 2 x 2 tile blocks staged through LDS (HBM traffic halves)
         const int nb2 = (g.nb0 + 1) / 2, nblk = nb2 * (nb2 + 1) / 2;
@@ -2594,16 +2614,29 @@ void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *a
         hipLaunchKernelGGL(grad_kinv_kernel, dim3((npairs + 3) / 4, Bc), dim3(256), 0, s, g, L, Kinv,
                            npairs);
     }
-    hipLaunchKernelGGL(grad_alpha_kernel, dim3((g.n0 + 1 + 3) / 4, Bc), dim3(256), 0, s, g, L,
-                       alpha, quad);
+    if (beside)
+        (void)hipStreamWaitEvent(s, join, 0);
+    else
+        hipLaunchKernelGGL(grad_alpha_kernel, dim3((g.n0 + 1 + 3) / 4, Bc), dim3(256), 0, s, g, L,
+                           alpha, quad);
 }
 
 void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
                           const double *alpha, const double *quad, double *partials, double *grad,
-                          double *logml, int Bc, const DevSpec &sp, hipStream_t s,
-                          const int32_t *items, const int32_t *bucket_counts) {
+                          double *logml, int Bc, const DevSpec &sp, hipStream_t s0,
+                          const int32_t *items, const int32_t *bucket_counts, hipStream_t side,
+                          hipEvent_t fork, hipEvent_t join) {
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
     int nparts = ntri;
+    // size classes of a SMALL chunk alternate between the main and the side stream: each is a few
+    // rounds of the chip with a ragged last one, and they touch different items
+    const bool two = side && fork && join && items && Bc <= 512;
+    int nlaunched = 0;
+    hipStream_t s = s0;
+    if (two) {
+        (void)hipEventRecord(fork, s0);
+        (void)hipStreamWaitEvent(side, fork, 0);
+    }
     if (g.lattice && p.dtab) {
         const int split = grad_contract_split(ntri, Bc);
         nparts = ntri * split;
@@ -2616,6 +2649,7 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
         for (int bk = 0; bk < GRAD_BUCKETS; ++bk) {
             const int nb = cnt[bk];
             if (nb <= 0) continue;
+            s = (two && (nlaunched++ & 1)) ? side : s0;
             const dim3 grid(ntri * split, nb), blk(256);
 #define NGP_LAUNCH_LISTS(...)                                                                    \
     hipLaunchKernelGGL((grad_contract_lists_kernel<__VA_ARGS__>), grid, blk, 0, s, g, p, Kinv, alpha, \
@@ -2637,10 +2671,14 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
             if (it) it += nb;
         }
     } else {
-        hipLaunchKernelGGL(grad_contract_kernel, dim3(ntri, Bc), dim3(256), 0, s, g, p.progs, p.t0,
+        hipLaunchKernelGGL(grad_contract_kernel, dim3(ntri, Bc), dim3(256), 0, s0, g, p.progs, p.t0,
                            Kinv, alpha, partials, ntri, sp);
     }
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3(Bc), dim3(128), 0, s, g, p.progs, partials, quad,
+    if (two) {
+        (void)hipEventRecord(join, side);
+        (void)hipStreamWaitEvent(s0, join, 0);
+    }
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(Bc), dim3(128), 0, s0, g, p.progs, partials, quad,
                        p.logdet, grad, logml, nparts);
 }
 
