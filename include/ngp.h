@@ -335,6 +335,15 @@ typedef struct ngp_profile {
     double   flops[NGP_NUM_KERNEL_CLASSES];    /* algorithmic flops executed   */
     double   bytes[NGP_NUM_KERNEL_CLASSES];    /* algorithmic HBM bytes        */
 } ngp_profile;
+/* Storage option of staged fp64 value jobs (on by default).  On a regular series (the main
+ * block's dates at a constant lattice stride) the covariance matrix of a stationary kernel tree is
+ * Toeplitz, K_ik = f(|i - k|): such an item's tiles below the block diagonal are then never
+ * written to HBM — the column sweep reads the 127 table entries of a tile from LDS where it would
+ * have read the stored 64 x 64 tile.  The values are the same table entries the fill would have
+ * stored, so every result is bit-identical with the option off (tests/test_toeplitz_gpu.py); off
+ * exists for that comparison and for A/B timing.  Applies to jobs staged after the call.       */
+ngp_status ngp_set_toeplitz(ngp_ctx *ctx, int32_t on);
+
 ngp_status ngp_profile_enable(ngp_ctx *ctx, int32_t on);
 ngp_status ngp_profile_reset(ngp_ctx *ctx);
 ngp_status ngp_profile_get(ngp_ctx *ctx, ngp_profile *out);

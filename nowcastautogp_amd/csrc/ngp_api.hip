@@ -281,6 +281,7 @@ struct ngp_ctx {
     ngp_spec spec{};
     std::mutex mu;
     bool profiling = false;
+    bool toeplitz = true;   // ngp_set_toeplitz
     ngp_profile prof{};
     size_t mem_cap = 0;  // bytes the factor storage of one job may take
     // caching allocator: repeated jobs of the same shape (the SMC/MCMC loop, the steps of a
@@ -484,6 +485,12 @@ extern "C" ngp_status ngp_get_spec(const ngp_ctx *c, ngp_spec *s) {
     return NGP_OK;
 }
 
+extern "C" ngp_status ngp_set_toeplitz(ngp_ctx *c, int32_t on) {
+    if (!c) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->toeplitz = on != 0;
+    return NGP_OK;
+}
 extern "C" ngp_status ngp_profile_enable(ngp_ctx *c, int32_t on) {
     if (!c) return NGP_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -639,6 +646,7 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
             pi.progs += h0;
             pi.logdet += h0;
             pi.info += h0;
+            if (pi.tab) pi.tab += (size_t)h0 * g.maxstat * g.R;   // read by the column kernels (toep)
             if (pi.splitk_part) pi.splitk_part += (size_t)h0 * SPLITK_SLOTS * 4 * 64 * 64;
             if (i == 0) {
                 factor_chunk(ln, g, pi, h1 - h0, tm, dinv_step, sp, order_buf, order_prev, true);
@@ -659,6 +667,8 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
         return;
     }
     const double nrows_aux = (double)g.naux;
+    const double lazy_frac =
+        (g.toep && p0.n_fill_single > 0 && !mixed) ? std::min(1.0, (double)p0.n_fill_single / bc) : 0.0;
     bool ahead_pending = false;
     // An odd number of block columns: column 0 goes alone (a FULL step without a k-loop: only the
     // solve) and the pairs start at column 1.  Pairing from column 0 leaves the LAST column alone,
@@ -723,6 +733,13 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
         if (fat) {  // + column jj+1 partial sums from the same rows
             fl += 2.0 * NB * rows_kc;
             by += 8.0 * (NB * k + 2.0 * rows * NB);
+        }
+        // Toeplitz jobs: the first step that touches a main tile of a single-table item reads 127
+        // table entries instead of the stored tile (the sibling wave of the first row tile works
+        // on the stored diagonal tile)
+        if (lazy_frac > 0.0 && (fat || (mode == COL_FULL && jj == 0))) {
+            const double rm = (double)(g.n0 - (jj + 1) * NB);
+            by -= lazy_frac * 8.0 * NB * (rm + (fat ? std::max(0.0, rm - NB) : 0.0));
         }
         // class 0: the LDS-DMA kernel of the fat steps (the dominant kernel, the roofline figure);
         // class 6: the direct-load kernel of the thin / full steps
@@ -799,6 +816,7 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     g.maxstat = std::max(maxstat, 1);
     g.maxcp = std::max(maxcp, 1);
     std::vector<int32_t> h_q;
+    int32_t toep_stride = 0;
     if (g.n0 > 0) {
         std::vector<double> allt((size_t)g.npts);
         for (int i = 0; i < n; ++i) allt[(size_t)i] = t[i];
@@ -810,11 +828,24 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
             g.lattice = 1;
             g.h = hh;
             g.R = R;
+            // the main block at a constant lattice stride (a regular series — every one the
+            // reference's tests and vignettes fit): K of a stationary tree is Toeplitz there and
+            // its off-diagonal tiles are never stored (JobGeom::toep).  fp64 value jobs with at
+            // least one tile below the diagonal; mixed precision keeps every tile (its shadow
+            // copies and tile maxima come from the stored rows).
+            if (g.nb0 >= 2) {
+                const long st0 = (long)h_q[1] - (long)h_q[0];
+                bool reg = st0 != 0;
+                for (int i = 2; i < g.n0 && reg; ++i)
+                    reg = (long)h_q[(size_t)i] - (long)h_q[(size_t)i - 1] == st0;
+                if (reg) toep_stride = (int32_t)std::labs(st0);
+            }
         }
     }
 
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
+    if (c->toeplitz && c->spec.precision != NGP_PREC_MIXED) g.toep = toep_stride;
     ngp_job *j = new (std::nothrow) ngp_job();
     if (!j) return NGP_ERR_TOO_LARGE;
     j->ctx = c;
@@ -1155,8 +1186,10 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
             }
             if (g.lattice)
                 tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
+            // Toeplitz jobs: single-table items store their diagonal tiles and aux rows only
             const double fill_elems =
-                (double)bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0);
+                (double)bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + nrows_aux * g.n0) -
+                (g.toep ? (double)p.n_fill_single * ((double)g.n0 * (g.n0 - NB) / 2.0) : 0.0);
             tm.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, s); });
             if (mixed) HIPCHK(hipMemsetAsync(order_prev, 0, 4 * (size_t)bc, s));
             factor_chunk(ln, g, p, bc, tm, mstep, mixed ? &sp : nullptr, (int32_t *)order_buf,

@@ -420,15 +420,22 @@ __device__ __forceinline__ void stage_mstrips(double *lds_m, const double *mstri
 // SYNTH (gradient jobs): the identity block of the aux rows [I ; y'] is never written to memory
 // by the fill; a tile of it that no step has touched yet is synthesised here instead of read —
 // synth = 1: zeros, 2: the identity (the tile on the block diagonal), 0: read as usual.
+// ksl (JobGeom::toep, single-table items, a tile no step has touched yet): the tile was never
+// written — K[i][jj] = ksl[63 + i - jj], the 127 table entries of the tile's lattice distances,
+// staged in LDS by the caller (toep_slice); null: read the stored tile.
 template <bool SHADOW = false, bool SYNTH = false, class Probe = NoProbe>
 __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], double *Lr,
                                                     const double *lds_m, long ld, int kmax,
                                                     int lane, double *buf, Probe &probe,
                                                     float *Lr32 = nullptr,
-                                                    float *tmax_out = nullptr, int synth = 0) {
+                                                    float *tmax_out = nullptr, int synth = 0,
+                                                    const double *ksl = nullptr) {
     double amax = 0.0;
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;          // row of S' inside a 16-tile
+    // 63 + i - jj = [15 + ((n16 + 4r) & 15) - jj0] + 16 (it - jt + 3): a per-lane base and a
+    // compile-time offset
+    const double *ksl0 = ksl ? ksl + 15 - jj0 : nullptr;
     // K' of the next 16-row group is requested before this group's product starts, so that its
     // round trip runs under the MFMAs (rows of different groups never overlap)
     double kv[4][4];
@@ -444,7 +451,8 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
                         continue;
                     }
                 }
-                kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
+                if (ksl0) kv[jt][r] = ksl0[((n16 + 4 * r) & 15) + 16 * (it - jt + 3)];
+                else kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
             }
     };
     load_k(0);
@@ -518,15 +526,29 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
 // written back: written as `*e -= x` per element, hipcc orders every load behind the previous
 // store (64 dependent round trips per tile: 35 us of a fat workgroup's 270, scripts/fat_phases.py).
 // fresh (gradient jobs): the tile is an untouched zero tile of the identity block — nothing is read
+// ksl: the tile was never written (see solve_and_store_lds) — tile = ksl[63 + i - jj] - S'[jj][i]
 __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, int c0,
                                                        const double (*acc4)[4][4], int lane,
-                                                       bool fresh = false) {
+                                                       bool fresh = false,
+                                                       const double *ksl = nullptr) {
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;
     double *base = rows + c0 + jj0;
     long roff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) roff[r] = (long)((n16 + 4 * r) & 15) * ld;
+    if (ksl) {
+        const double *ksl0 = ksl + 15 - jj0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    base[(long)(16 * it) * ld + roff[r] + 16 * jt] =
+                        ksl0[((n16 + 4 * r) & 15) + 16 * (it - jt + 3)] - acc4[jt][it][r];
+        return;
+    }
     if (fresh) {
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -559,6 +581,16 @@ __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, in
     }
 }
 
+// JobGeom::toep: the 127 table entries of a tile whose first row is `drow` lattice points below
+// its first column (drow >= 64), into the wave's 128-double LDS slice: ksl[x] = tab[toep (drow - 63 + x)]
+__device__ __forceinline__ void toep_slice(double *ksl, const double *tab, int toep, int drow,
+                                           int lane) {
+    const int d0 = drow - 63;
+    ksl[lane] = tab[(long)toep * (d0 + lane)];
+    if (lane < 63) ksl[64 + lane] = tab[(long)toep * (d0 + 64 + lane)];
+}
+constexpr int TOEP_LDS_BYTES = 4 * 128 * 8;   // one slice per wave
+
 struct ColStep {
     int j;        // block column being finished
     int k0;       // first k not yet accumulated into column j
@@ -566,6 +598,8 @@ struct ColStep {
     int ntiles;   // nmain + aux tiles
     int groups;   // workgroups per item
     int splits;   // fat steps of small batches: workgroups that share one tile pair's k-range (1: none)
+    int first_touch;   // FAT / FULL steps: no earlier step has touched the main tiles of this column
+                       // (JobGeom::toep: the tiles of single-table items were never written)
     // mixed-precision jobs: a tile product runs in fp32 iff max|A| max|B| <= c32 (noise + jitter),
     // c32 = mixed_tau / (64 * 2^-24)
     double c32, jitter;
@@ -580,10 +614,13 @@ __device__ __forceinline__ long tmax_index(const JobGeom &g, int row_tile, int c
 // IDENT (gradient jobs, aux rows [I ; y']): identity tile a joins from block column a on, its
 // k-loop starts at 64 a, and a tile of the identity block that no step has written yet is
 // synthesised, not read (the fill leaves the identity block out).
-template <bool MIXED, bool IDENT = false>
+// TOEP (JobGeom::toep, the FULL step of column 0 of an odd block-column count): the tiles of
+// single-table items come from the table slice; an instantiation of its own, so that the ordinary
+// one keeps its registers (with the slice path compiled in it spilled 136 B per lane).
+template <bool MIXED, bool IDENT = false, bool TOEP = false>
 __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p, int Bc,
                                                           ColStep st) {
-    __shared__ __attribute__((aligned(16))) char epi[EPI_LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char epi[EPI_LDS_BYTES + (TOEP ? TOEP_LDS_BYTES : 0)];
     const int wg = blockIdx.x;
     const int xcd = wg & 7, idx = wg >> 3;   // blocks b and b+8 share an XCD (speed only)
     const int slot = (idx / st.groups) * 8 + xcd;
@@ -631,6 +668,17 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     const double *pa = Lj + (long)r16 * ld + 2 * q;
     const double *pb = Lr + (long)r16 * ld + 2 * q;        // B operand: rows of this tile
     if (valid) gemm_rows<4>(acc4, pa, pb, ld, kbeg, kmax);
+    // JobGeom::toep: the main tiles of a single-table item were never written (FULL step of
+    // column 0: nothing has touched them) — their values come from the wave's table slice
+    const double *ksl = nullptr;
+    if constexpr (TOEP) {
+        if (valid && tile < st.nmain && prog_single_table(p.progs + item)) {
+            double *sl = reinterpret_cast<double *>(epi + EPI_LDS_BYTES) + wave * 128;
+            toep_slice(sl, p.tab + (long)item * g.maxstat * g.R, g.toep, (int)(rowbase - kmax),
+                       lane);
+            ksl = sl;
+        }
+    }
     stage_mstrips(reinterpret_cast<double *>(epi), p.dinv + (long)item * (NB * NB), tid);
     __syncthreads();
     if (!valid) return;
@@ -646,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
         solve_and_store_lds<false, IDENT>(
             acc4, Lr, reinterpret_cast<const double *>(epi), ld, kmax, lane,
             reinterpret_cast<double *>(epi + EPI_M_BYTES + wave * EPI_WAVE_BYTES), probe, nullptr,
-            nullptr, synth);
+            nullptr, synth, ksl);
     }
 }
 
@@ -865,6 +913,14 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     const long ld = g.ld;
     double *Lit = p.L + (long)item * g.item_stride;
     const int kmax = j * NB;
+    // JobGeom::toep: the main tiles of a single-table item below the block diagonal were never
+    // written; a fat step is the first to touch its two columns' tiles (the sibling wave of the
+    // first row tile works on the diagonal tile (j+1, j+1), which IS stored: it carries the noise)
+    bool lazy = false;
+    if constexpr (!MIXED && !IDENT) {
+        lazy = g.toep && st.first_touch && valid && tile < st.nmain && !(col && tile == 0) &&
+               prog_single_table(p.progs + item);
+    }
     // gradient jobs (aux rows [I ; y']): identity tile a is zero left of block column a.  The two
     // tiles of a workgroup share the staged k-range, so it starts at the smaller of their starts;
     // a workgroup whose tiles are all still zero leaves before the first barrier.
@@ -1219,8 +1275,16 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     }
     // the staging buffers are free (every wave passed the k-loop's last barrier): M strips go to
     // LDS for both tiles of the workgroup
-    static_assert(EPI_LDS_BYTES <= 2 * STAGE, "epilogue LDS must fit the stage buffers");
+    static_assert(EPI_LDS_BYTES + TOEP_LDS_BYTES <= 2 * STAGE,
+                  "epilogue LDS must fit the stage buffers");
     probe.mark(3);
+    const double *ksl = nullptr;
+    if (lazy) {
+        double *sl = reinterpret_cast<double *>(smem + EPI_LDS_BYTES) + wave * 128;
+        toep_slice(sl, p.tab + (long)item * g.maxstat * g.R, g.toep,
+                   (int)(tile_row0(tile) - (col ? kmax + NB : kmax)), lane);
+        ksl = sl;
+    }
     stage_mstrips(reinterpret_cast<double *>(smem), p.dinv + (long)item * (NB * NB), tid);
     __syncthreads();
     probe.mark(4);
@@ -1228,7 +1292,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 
     double *Lr = Lit + tile_row0(tile) * ld;
     if (col) {
-        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane, IDENT && synth != 0);
+        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane, IDENT && synth != 0, ksl);
     } else if constexpr (MIXED) {
         const int rt = (tile < st.nmain) ? j + 1 + tile : g.nb0 + (tile - st.nmain);
         solve_and_store_lds<true>(
@@ -1240,7 +1304,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
         solve_and_store_lds<false, IDENT>(
             acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
             reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES), probe, nullptr,
-            nullptr, synth);
+            nullptr, synth, ksl);
     }
     probe.mark(5);
     probe.drain();       // stores retired (vmcnt(0))
@@ -1272,6 +1336,7 @@ void launch_chol_col_t(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int 
     if (st.ntiles <= 0) return;
     const int bpad = (Bc + 7) / 8 * 8;
     const dim3 blk(256);
+    st.first_touch = (mode == COL_FAT || (mode == COL_FULL && k0 == 0 && j == 0)) ? 1 : 0;
     if (mode == COL_FAT) {
         st.groups = (st.ntiles + 1) / 2;
         const dim3 grid(st.groups * bpad);
@@ -1314,6 +1379,8 @@ void launch_chol_col_t(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int 
             hipLaunchKernelGGL(chol_col_kernel<true>, grid, blk, 0, s, g, p, Bc, st);
         else if (g.aux_identity)
             hipLaunchKernelGGL((chol_col_kernel<false, true>), grid, blk, 0, s, g, p, Bc, st);
+        else if (g.toep && st.first_touch)
+            hipLaunchKernelGGL((chol_col_kernel<false, false, true>), grid, blk, 0, s, g, p, Bc, st);
         else
             hipLaunchKernelGGL(chol_col_kernel<false>, grid, blk, 0, s, g, p, Bc, st);
     }

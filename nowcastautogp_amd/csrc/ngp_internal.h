@@ -51,6 +51,11 @@ struct DevProgram {
     uint8_t tb_last[MAX_TABLES];        //  range of the full program = one subtree)
 };
 static_assert(sizeof(DevProgram) % 8 == 0, "DevProgram is copied as 8-byte words");
+// the whole tree is stationary: its reduced program is ONE table lookup (fill_single_kernel; with
+// JobGeom::toep the items whose off-diagonal tiles are never materialised)
+__host__ __device__ inline bool prog_single_table(const DevProgram *P) {
+    return P->n_rops == 1 && P->rops[0] == OP_TABLE;
+}
 
 struct DevSpec {
     int32_t se_form, periodic_form, cp_form, precision;
@@ -80,6 +85,11 @@ struct JobGeom {
     int32_t n_real;    // main-block points that are data; rows/cols beyond are identity padding
     int32_t aux_identity;  // 1: aux rows are [I_n0 ; y'] (gradient path: W = L^-T)
     int32_t maxops;    // longest program of the batch (gradient jobs: picks the contraction kernel)
+    int32_t toep;      // > 0: the main-block points sit on the lattice at a constant stride (q_i = q_0
+                       // +- toep i), so K of a stationary tree is Toeplitz: K_ik = tab[toep |i - k|].  The
+                       // fill then writes only the diagonal tiles and the aux rows of single-table items
+                       // and the column kernels read a tile's 127 table entries from LDS where they
+                       // would have read the stored tile (staged fp64 value jobs only; else 0)
     double  h;         // lattice step
     int64_t ld;        // row stride of the factor storage (= n0)
     int64_t item_stride;  // elements per item in the factor storage

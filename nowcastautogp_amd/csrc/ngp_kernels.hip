@@ -515,7 +515,18 @@ __global__ __launch_bounds__(256) void fill_single_kernel(JobGeom g, ChunkPtrs p
     const int tile = blockIdx.x;
     int r, c;
     bool aux = false;
-    if (tile < ntri) {
+    if (g.toep) {
+        // Toeplitz jobs: only the diagonal tiles (they carry the noise) and the aux rows are
+        // stored; the column kernels take every other tile from the table (toep_slice)
+        if (tile < g.nb0) {
+            r = c = tile;
+        } else {
+            const int a = tile - g.nb0;
+            r = a / g.nb0;
+            c = a % g.nb0;
+            aux = true;
+        }
+    } else if (tile < ntri) {
         r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
         while ((r + 1) * (r + 2) / 2 <= tile) ++r;
         while (r * (r + 1) / 2 > tile) --r;
@@ -2496,8 +2507,9 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
                 hipLaunchKernelGGL(fill_chain_kernel, dim3(ntiles, p.n_fill_chain), dim3(256), 0, s,
                                    g, p, ntri, sp);
             if (p.n_fill_single > 0)
-                hipLaunchKernelGGL(fill_single_kernel, dim3(ntiles, p.n_fill_single), dim3(256), 0,
-                                   s, g, p, ntri, sp);
+                hipLaunchKernelGGL(fill_single_kernel,
+                                   dim3(g.toep ? ntiles - ntri + g.nb0 : ntiles, p.n_fill_single),
+                                   dim3(256), 0, s, g, p, ntri, sp);
         } else {
             ChunkPtrs q = p;
             q.fill_other = nullptr;

@@ -1,0 +1,106 @@
+"""Toeplitz storage of staged value jobs (include/ngp.h ``ngp_set_toeplitz``): on a regular series
+the off-diagonal tiles of a stationary tree are never written and the column sweep reads the table
+entries instead — the SAME values the fill would have stored, so every output must be bit-identical
+with the option off.  Shapes cover the FAT / THIN schedule (even block-column count), the FULL step
+of column 0 (odd count), the split-k and two-lane sweeps of small chunks, a ragged tail, per-item y
+rows, a lattice stride of two, and a series with a gap (option silently not applicable)."""
+import numpy as np
+import pytest
+
+from nowcastautogp_amd import _lib
+from nowcastautogp_amd.synthetic import make_workload
+from oracle import oracle_np
+from tests.util import TOL_LOGML, TOL_PRED, check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import __graft_entry__ as ge
+    ge.build()
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _mixed_ensemble(w, extra=()):
+    """the workload's sampled trees plus hand-made stationary ones, so that single-table items,
+    chain items and interpreter items share every launch"""
+    se = (np.array([3], np.int32), np.array([0.21, 0.9]), 3e-3)
+    per = (np.array([5], np.int32), np.array([0.8, 0.13, 0.7]), 2e-2)
+    ge_ = (np.array([4, 5, 6], np.int32), np.array([0.3, 1.3, 0.5, 0.9, 0.25, 0.4]), 1e-3)
+    return list(w.programs) + [se, per, ge_] + list(extra)
+
+
+def _both(ctx, call):
+    ctx.set_toeplitz(True)
+    on = call()
+    ctx.set_toeplitz(False)
+    try:
+        off = call()
+    finally:
+        ctx.set_toeplitz(True)
+    return on, off
+
+
+@pytest.mark.parametrize("n,P,D", [(256 + 5, 6, 3),      # 4 block columns: two fat / thin pairs
+                                   (192 + 17, 5, 2),     # 3: FULL step of column 0, then a pair
+                                   (128, 4, 1),          # 2: one pair, no tail
+                                   (1024 + 1, 9, 4),     # 16: split-k fat steps of a small chunk
+                                   (1600 + 3, 64, 2)])   # 25: two-lane sweep, odd count
+def test_nowcast_outputs_are_bit_identical_with_the_option_off(ctx, n, P, D):
+    w = make_workload("C2", n=n, P=P, D=D, d=2, m=7)
+    progs = _mixed_ensemble(w)
+    on, off = _both(ctx, lambda: ctx.nowcast_batch(progs, w.t, w.y, w.t_add, w.y_add, w.t_new))
+    for k in ("logml_base", "logml_full", "mu", "sigma", "info"):
+        assert np.array_equal(on[k], off[k]), k
+    assert not on["info"].any()
+    # and the answers are the oracle's
+    tt = np.concatenate([w.t, w.t_add])
+    for p in (0, len(progs) - 3, len(progs) - 1):
+        cond = np.linalg.cond(oracle_np.cov(progs[p], tt, tt, True))
+        lb, lf, mu, sg, _ = oracle_np.nowcast(progs[p], w.t, w.y, w.t_add, w.y_add, w.t_new)
+        check("toeplitz storage: logml vs oracle", on["logml_full"][p], lf, TOL_LOGML, cond)
+        check("toeplitz storage: predictive vs oracle", on["mu"][p], mu, TOL_PRED, cond)
+        check("toeplitz storage: predictive vs oracle", on["sigma"][p], sg, TOL_PRED, cond)
+
+
+def test_per_item_y_rows_and_predict(ctx):
+    w = make_workload("C2", n=448 + 9, P=7, D=1, d=1, m=5)
+    progs = _mixed_ensemble(w)
+    rng = np.random.default_rng(5)
+    Y = w.y[None, :] + 0.01 * rng.standard_normal((len(progs), w.n))
+    on, off = _both(ctx, lambda: ctx.predict_batch(progs, w.t, Y, w.t_new))
+    for a, b in zip(on, off):      # (mu, sigma, logml, info)
+        assert np.array_equal(a, b)
+    assert not on[3].any()
+    lo, lf = _both(ctx, lambda: ctx.logml_batch(progs, w.t, Y))
+    assert np.array_equal(lo[0], lf[0]) and np.array_equal(lo[1], lf[1])
+
+
+def test_lattice_stride_two_and_a_gap(ctx):
+    w = make_workload("C2", n=320, P=4, D=2, d=1, m=4)
+    progs = _mixed_ensemble(w)
+    # every second lattice point in the main block (stride 2), forecast points on the fine lattice
+    h = 1.0 / 700.0
+    t = 2 * h * np.arange(w.n)
+    t_add = np.array([t[-1] + 2 * h])
+    t_new = t_add[-1] + h * np.arange(1, 5)
+    on, off = _both(ctx, lambda: ctx.nowcast_batch(progs, t, w.y, t_add, w.y_add, t_new))
+    for k in ("logml_full", "mu", "sigma"):
+        assert np.array_equal(on[k], off[k]), k
+    tt = np.concatenate([t, t_add])
+    cond = np.linalg.cond(oracle_np.cov(progs[-3], tt, tt, True))
+    ref = oracle_np.nowcast(progs[-3], t, w.y, t_add, w.y_add, t_new)
+    check("toeplitz storage: logml vs oracle", on["logml_full"][-3], ref[1], TOL_LOGML, cond)
+    # one missing week inside the main block: not Toeplitz by index, the stored path runs
+    tg = t.copy()
+    tg[100:] += 2 * h
+    on, off = _both(ctx, lambda: ctx.nowcast_batch(progs, tg, w.y, t_add + 2 * h, w.y_add, t_new + 2 * h))
+    for k in ("logml_full", "mu", "sigma"):
+        assert np.array_equal(on[k], off[k]), k
+    tt = np.concatenate([tg, t_add + 2 * h])
+    cond = np.linalg.cond(oracle_np.cov(progs[-2], tt, tt, True))
+    ref = oracle_np.nowcast(progs[-2], tg, w.y, t_add + 2 * h, w.y_add, t_new + 2 * h)
+    check("toeplitz storage: logml vs oracle", on["logml_full"][-2], ref[1], TOL_LOGML, cond)
