@@ -411,8 +411,8 @@ def main():
     ap.add_argument("--mode", default="predict", choices=["predict", "grad"],
                     help="grad: a step is one logml + gradient call over the items (HMC leapfrog)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items in the CPU sample (0: auto)")
-    ap.add_argument("--no-toeplitz", action="store_true",
-                    help="store every covariance tile (ngp_set_toeplitz off): same results, for A/B timing")
+    ap.add_argument("--no-structured-storage", action="store_true",
+                    help="store every covariance tile (ngp_set_structured_storage off): same results, for A/B timing")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed steps: no shared-K / resident-factor / fit / CPU legs, so a "
                          "rocprofv3 --stats of this command holds exactly the launches the roofline "
@@ -456,8 +456,8 @@ def main():
     grad_mode = args.mode == "grad"
     dev = torch.device("cuda", local_rank)
     ctx = _lib.Context(local_rank)
-    if args.no_toeplitz:
-        ctx.set_toeplitz(False)
+    if args.no_structured_storage:
+        ctx.set_structured_storage(False)
     job = ka = None
     evals_per_item = 1
     if sharded:

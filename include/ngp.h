@@ -337,12 +337,13 @@ typedef struct ngp_profile {
 } ngp_profile;
 /* Storage option of staged fp64 value jobs (on by default).  On a regular series (the main
  * block's dates at a constant lattice stride) the covariance matrix of a stationary kernel tree is
- * Toeplitz, K_ik = f(|i - k|): such an item's tiles below the block diagonal are then never
- * written to HBM — the column sweep reads the 127 table entries of a tile from LDS where it would
- * have read the stored 64 x 64 tile.  The values are the same table entries the fill would have
- * stored, so every result is bit-identical with the option off (tests/test_toeplitz_gpu.py); off
- * exists for that comparison and for A/B timing.  Applies to jobs staged after the call.       */
-ngp_status ngp_set_toeplitz(ngp_ctx *ctx, int32_t on);
+ * Toeplitz, K_ik = f(|i - k|): 127 numbers describe a 64 x 64 tile exactly.  Such an item's tiles
+ * below the block diagonal are then never written to HBM — the column sweep regenerates a tile
+ * from those numbers in LDS where it would have read the stored tile.  The values are the table
+ * entries the fill would have stored, so every result is bit-identical with the option off
+ * (tests/test_structured_storage_gpu.py); off exists for that comparison and for A/B timing.
+ * Applies to jobs staged after the call.                                                        */
+ngp_status ngp_set_structured_storage(ngp_ctx *ctx, int32_t on);
 
 ngp_status ngp_profile_enable(ngp_ctx *ctx, int32_t on);
 ngp_status ngp_profile_reset(ngp_ctx *ctx);

@@ -31,7 +31,7 @@ SYMBOLS = (
     "ngp_comm_destroy", "ngp_weights_allgather_normalize",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
     "ngp_job_mixed_stats", "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
-    "ngp_factor_destroy", "ngp_mixture_sample", "ngp_set_toeplitz", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
+    "ngp_factor_destroy", "ngp_mixture_sample", "ngp_set_structured_storage", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
     "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
     "ngp_selftest_mfma_f32_layout",
 )
@@ -108,7 +108,7 @@ def load():
         "ngp_factor_destroy": (None, [vp]),
         "ngp_mixture_sample": (i32, [vp, i32, i32, i32, f64p, f64p, f64p, i32, C.c_uint64, f64p,
                                      i32p, i32p]),
-        "ngp_set_toeplitz": (i32, [vp, i32]),
+        "ngp_set_structured_storage": (i32, [vp, i32]),
         "ngp_profile_enable": (i32, [vp, i32]),
         "ngp_profile_reset": (i32, [vp]),
         "ngp_profile_get": (i32, [vp, C.POINTER(NgpProfile)]),
@@ -506,9 +506,9 @@ class Context:
         return Job(self, h, ka.n, D, m, (ka, t, y, t_add, y_add, t_new))
 
     # ---- measurement ----------------------------------------------------------------------
-    def set_toeplitz(self, on=True):
+    def set_structured_storage(self, on=True):
         """Storage option of staged value jobs (include/ngp.h): results are bit-identical either way."""
-        _chk(load().ngp_set_toeplitz(self._h, int(bool(on))), "ngp_set_toeplitz")
+        _chk(load().ngp_set_structured_storage(self._h, int(bool(on))), "ngp_set_structured_storage")
 
     def profile_enable(self, on=True):
         _chk(load().ngp_profile_enable(self._h, int(bool(on))), "ngp_profile_enable")

@@ -281,7 +281,7 @@ struct ngp_ctx {
     ngp_spec spec{};
     std::mutex mu;
     bool profiling = false;
-    bool toeplitz = true;   // ngp_set_toeplitz
+    bool toeplitz = true;   // ngp_set_structured_storage
     ngp_profile prof{};
     size_t mem_cap = 0;  // bytes the factor storage of one job may take
     // caching allocator: repeated jobs of the same shape (the SMC/MCMC loop, the steps of a
@@ -485,7 +485,7 @@ extern "C" ngp_status ngp_get_spec(const ngp_ctx *c, ngp_spec *s) {
     return NGP_OK;
 }
 
-extern "C" ngp_status ngp_set_toeplitz(ngp_ctx *c, int32_t on) {
+extern "C" ngp_status ngp_set_structured_storage(ngp_ctx *c, int32_t on) {
     if (!c) return NGP_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     c->toeplitz = on != 0;
@@ -859,11 +859,12 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
         return s;
     };
     const int ny = g.y_shared ? 1 : P;
+    // the fill kernel of every item: one table for the whole tree (in a Toeplitz job the
+    // structured items, prog_structure) / chain programs / the rest
     if (g.lattice && g.n0 > 0)
         for (int i = 0; i < P; ++i)
-            (hp[(size_t)i].n_rops == 1 && hp[(size_t)i].rops[0] == OP_TABLE
-                 ? j->fill_single
-                 : hp[(size_t)i].rchain ? j->fill_chain : j->fill_other)
+            (prog_single_table(&hp[(size_t)i]) ? j->fill_single
+                                                : hp[(size_t)i].rchain ? j->fill_chain : j->fill_other)
                 .push_back(i);
     // ONE device arena for everything that crosses the bus, inputs first, outputs last:
     //   [programs | t0 | taux | y0 | ya | lattice indices | fill lists | logdet | info |

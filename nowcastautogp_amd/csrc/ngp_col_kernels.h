@@ -420,9 +420,9 @@ __device__ __forceinline__ void stage_mstrips(double *lds_m, const double *mstri
 // SYNTH (gradient jobs): the identity block of the aux rows [I ; y'] is never written to memory
 // by the fill; a tile of it that no step has touched yet is synthesised here instead of read —
 // synth = 1: zeros, 2: the identity (the tile on the block diagonal), 0: read as usual.
-// ksl (JobGeom::toep, single-table items, a tile no step has touched yet): the tile was never
+// ksl (JobGeom::toep, structured items, a tile no step has touched yet): the tile was never
 // written — K[i][jj] = ksl[63 + i - jj], the 127 table entries of the tile's lattice distances,
-// staged in LDS by the caller (toep_slice); null: read the stored tile.
+// staged in LDS by the caller (struct_slice); null: read the stored tile.
 template <bool SHADOW = false, bool SYNTH = false, class Probe = NoProbe>
 __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], double *Lr,
                                                     const double *lds_m, long ld, int kmax,
@@ -436,10 +436,19 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
     // 63 + i - jj = [15 + ((n16 + 4r) & 15) - jj0] + 16 (it - jt + 3): a per-lane base and a
     // compile-time offset
     const double *ksl0 = ksl ? ksl + 15 - jj0 : nullptr;
-    // K' of the next 16-row group is requested before this group's product starts, so that its
-    // round trip runs under the MFMAs (rows of different groups never overlap)
     double kv[4][4];
+    // the source is tested once per 16-row group, outside the element loops: tested per element it
+    // puts every load into a basic block of its own and the sixteen loads of a group are no longer
+    // issued together
     auto load_k = [&](int it) {
+        if (ksl0) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    kv[jt][r] = ksl0[((n16 + 4 * r) & 15) + 16 * (it - jt + 3)];
+            return;
+        }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -451,8 +460,7 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
                         continue;
                     }
                 }
-                if (ksl0) kv[jt][r] = ksl0[((n16 + 4 * r) & 15) + 16 * (it - jt + 3)];
-                else kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
+                kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
             }
     };
     load_k(0);
@@ -581,13 +589,15 @@ __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, in
     }
 }
 
-// JobGeom::toep: the 127 table entries of a tile whose first row is `drow` lattice points below
-// its first column (drow >= 64), into the wave's 128-double LDS slice: ksl[x] = tab[toep (drow - 63 + x)]
-__device__ __forceinline__ void toep_slice(double *ksl, const double *tab, int toep, int drow,
-                                           int lane) {
-    const int d0 = drow - 63;
-    ksl[lane] = tab[(long)toep * (d0 + lane)];
-    if (lane < 63) ksl[64 + lane] = tab[(long)toep * (d0 + 64 + lane)];
+// JobGeom::toep: the 127 table entries a structured item's tile (rows row0.., columns col0.. of the
+// main block, row0 >= col0 + 64) is regenerated from, into the wave's LDS slice:
+// ksl[x] = tab[toep (row0 - col0 - 63 + x)]
+__device__ __forceinline__ void struct_slice(double *ksl, const JobGeom &g, const ChunkPtrs &p,
+                                             int item, int row0, int col0, int lane) {
+    const double *tab = p.tab + (long)item * g.maxstat * g.R;
+    const int d0 = row0 - col0 - 63;
+    ksl[lane] = tab[(long)g.toep * (d0 + lane)];
+    if (lane < 63) ksl[64 + lane] = tab[(long)g.toep * (d0 + 64 + lane)];
 }
 constexpr int TOEP_LDS_BYTES = 4 * 128 * 8;   // one slice per wave
 
@@ -672,10 +682,9 @@ __global__ __launch_bounds__(256, 2) void chol_col_kernel(JobGeom g, ChunkPtrs p
     // column 0: nothing has touched them) — their values come from the wave's table slice
     const double *ksl = nullptr;
     if constexpr (TOEP) {
-        if (valid && tile < st.nmain && prog_single_table(p.progs + item)) {
+        if (valid && tile < st.nmain && prog_structure(p.progs + item)) {
             double *sl = reinterpret_cast<double *>(epi + EPI_LDS_BYTES) + wave * 128;
-            toep_slice(sl, p.tab + (long)item * g.maxstat * g.R, g.toep, (int)(rowbase - kmax),
-                       lane);
+            struct_slice(sl, g, p, item, (int)rowbase, kmax, lane);
             ksl = sl;
         }
     }
@@ -916,10 +925,10 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     // JobGeom::toep: the main tiles of a single-table item below the block diagonal were never
     // written; a fat step is the first to touch its two columns' tiles (the sibling wave of the
     // first row tile works on the diagonal tile (j+1, j+1), which IS stored: it carries the noise)
-    bool lazy = false;
+    bool structured = false;
     if constexpr (!MIXED && !IDENT) {
-        lazy = g.toep && st.first_touch && valid && tile < st.nmain && !(col && tile == 0) &&
-               prog_single_table(p.progs + item);
+        if (g.toep && st.first_touch && valid && tile < st.nmain && !(col && tile == 0))
+            structured = prog_structure(p.progs + item) != 0;
     }
     // gradient jobs (aux rows [I ; y']): identity tile a is zero left of block column a.  The two
     // tiles of a workgroup share the staged k-range, so it starts at the smaller of their starts;
@@ -1279,10 +1288,9 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
                   "epilogue LDS must fit the stage buffers");
     probe.mark(3);
     const double *ksl = nullptr;
-    if (lazy) {
+    if (structured) {
         double *sl = reinterpret_cast<double *>(smem + EPI_LDS_BYTES) + wave * 128;
-        toep_slice(sl, p.tab + (long)item * g.maxstat * g.R, g.toep,
-                   (int)(tile_row0(tile) - (col ? kmax + NB : kmax)), lane);
+        struct_slice(sl, g, p, item, (int)tile_row0(tile), col ? kmax + NB : kmax, lane);
         ksl = sl;
     }
     stage_mstrips(reinterpret_cast<double *>(smem), p.dinv + (long)item * (NB * NB), tid);

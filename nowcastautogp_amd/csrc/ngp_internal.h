@@ -51,10 +51,20 @@ struct DevProgram {
     uint8_t tb_last[MAX_TABLES];        //  range of the full program = one subtree)
 };
 static_assert(sizeof(DevProgram) % 8 == 0, "DevProgram is copied as 8-byte words");
-// the whole tree is stationary: its reduced program is ONE table lookup (fill_single_kernel; with
-// JobGeom::toep the items whose off-diagonal tiles are never materialised)
+// the whole tree is stationary: its reduced program is ONE table lookup (fill_single_kernel)
 __host__ __device__ inline bool prog_single_table(const DevProgram *P) {
     return P->n_rops == 1 && P->rops[0] == OP_TABLE;
+}
+// Structured items (JobGeom::toep: their tiles below the block diagonal are never stored, the
+// column kernels regenerate them from 127 numbers in LDS):
+//   1  the whole tree is stationary        K_ik = tab[toep |i - k|]            (Toeplitz)
+//   0  anything else: stored
+// (A single Linear leaf, K_ik = bias + amp (t_i - c)(t_k - c), was built as a second kind — 17 % of
+// the bench ensemble, fill 35 -> 29 ms — and taken out again: with a second kind in the epilogue
+// the fat kernel, stored tiles included, ran 4-5 % slower, whichever way the two kinds shared the
+// code; profiles/r03/README.md.)
+__host__ __device__ inline int prog_structure(const DevProgram *P) {
+    return (P->n_rops == 1 && P->rops[0] == OP_TABLE) ? 1 : 0;
 }
 
 struct DevSpec {
@@ -87,9 +97,9 @@ struct JobGeom {
     int32_t maxops;    // longest program of the batch (gradient jobs: picks the contraction kernel)
     int32_t toep;      // > 0: the main-block points sit on the lattice at a constant stride (q_i = q_0
                        // +- toep i), so K of a stationary tree is Toeplitz: K_ik = tab[toep |i - k|].  The
-                       // fill then writes only the diagonal tiles and the aux rows of single-table items
-                       // and the column kernels read a tile's 127 table entries from LDS where they
-                       // would have read the stored tile (staged fp64 value jobs only; else 0)
+                       // fill then writes only the diagonal tiles and the aux rows of structured items
+                       // (prog_structure) and the column kernels regenerate a tile from 128 numbers in
+                       // LDS where they would have read the stored tile (staged fp64 value jobs; else 0)
     double  h;         // lattice step
     int64_t ld;        // row stride of the factor storage (= n0)
     int64_t item_stride;  // elements per item in the factor storage

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void fill_single_kernel(JobGeom g, ChunkPtrs p
     bool aux = false;
     if (g.toep) {
         // Toeplitz jobs: only the diagonal tiles (they carry the noise) and the aux rows are
-        // stored; the column kernels take every other tile from the table (toep_slice)
+        // stored; the column kernels take every other tile from the table (struct_slice)
         if (tile < g.nb0) {
             r = c = tile;
         } else {
@@ -540,7 +540,8 @@ __global__ __launch_bounds__(256) void fill_single_kernel(JobGeom g, ChunkPtrs p
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int col = c * NB + 2 * tx;
     const int q2a = p.qpts[col], q2b = p.qpts[col + 1];
-    const double diag = p.progs[item].noise + sp.jitter;
+    const DevProgram *P = p.progs + item;
+    const double diag = P->noise + sp.jitter;
     double *Lit = p.L + (long)item * g.item_stride;
     const double *tab = p.tab + (long)item * g.maxstat * g.R;   // slot 0: the tree's only table
     const int naux_t = g.da + g.m;

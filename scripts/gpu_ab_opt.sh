@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of ONE build with and without a bench.py option, interleaved on the SAME box.
-# Usage: gpurun -- bash scripts/gpu_ab_opt.sh --no-toeplitz [extra bench args]
+# Usage: gpurun -- bash scripts/gpu_ab_opt.sh --no-structured-storage [extra bench args]
 opt=$1; shift
 for r in 1 2; do
 for v in with without; do

@@ -1,9 +1,10 @@
-"""Toeplitz storage of staged value jobs (include/ngp.h ``ngp_set_toeplitz``): on a regular series
-the off-diagonal tiles of a stationary tree are never written and the column sweep reads the table
-entries instead — the SAME values the fill would have stored, so every output must be bit-identical
-with the option off.  Shapes cover the FAT / THIN schedule (even block-column count), the FULL step
-of column 0 (odd count), the split-k and two-lane sweeps of small chunks, a ragged tail, per-item y
-rows, a lattice stride of two, and a series with a gap (option silently not applicable)."""
+"""Structured storage of staged value jobs (include/ngp.h ``ngp_set_structured_storage``): on a
+regular series the off-diagonal tiles of a stationary tree (Toeplitz) are never written and the
+column sweep regenerates them from 127 table entries in LDS — the SAME values
+the fill would have stored, so every output must be bit-identical with the option off.  Shapes
+cover the FAT / THIN schedule (even block-column count), the FULL step of column 0 (odd count), the
+split-k and two-lane sweeps of small chunks, a ragged tail, per-item y rows, a lattice stride of
+two, and a series with a gap (option silently not applicable)."""
 import numpy as np
 import pytest
 
@@ -30,17 +31,19 @@ def _mixed_ensemble(w, extra=()):
     se = (np.array([3], np.int32), np.array([0.21, 0.9]), 3e-3)
     per = (np.array([5], np.int32), np.array([0.8, 0.13, 0.7]), 2e-2)
     ge_ = (np.array([4, 5, 6], np.int32), np.array([0.3, 1.3, 0.5, 0.9, 0.25, 0.4]), 1e-3)
-    return list(w.programs) + [se, per, ge_] + list(extra)
+    lin = (np.array([2], np.int32), np.array([0.37, 0.11, 0.8]), 4e-3)
+    lin2 = (np.array([2], np.int32), np.array([-0.2, 0.02, 1.7]), 5e-2)
+    return list(w.programs) + [lin, se, per, ge_, lin2] + list(extra)
 
 
 def _both(ctx, call):
-    ctx.set_toeplitz(True)
+    ctx.set_structured_storage(True)
     on = call()
-    ctx.set_toeplitz(False)
+    ctx.set_structured_storage(False)
     try:
         off = call()
     finally:
-        ctx.set_toeplitz(True)
+        ctx.set_structured_storage(True)
     return on, off
 
 
@@ -58,7 +61,7 @@ def test_nowcast_outputs_are_bit_identical_with_the_option_off(ctx, n, P, D):
     assert not on["info"].any()
     # and the answers are the oracle's
     tt = np.concatenate([w.t, w.t_add])
-    for p in (0, len(progs) - 3, len(progs) - 1):
+    for p in (0, len(progs) - 5, len(progs) - 3, len(progs) - 1):
         cond = np.linalg.cond(oracle_np.cov(progs[p], tt, tt, True))
         lb, lf, mu, sg, _ = oracle_np.nowcast(progs[p], w.t, w.y, w.t_add, w.y_add, w.t_new)
         check("toeplitz storage: logml vs oracle", on["logml_full"][p], lf, TOL_LOGML, cond)
