@@ -449,17 +449,23 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
                     kv[jt][r] = ksl0[((n16 + 4 * r) & 15) + 16 * (it - jt + 3)];
             return;
         }
+        if constexpr (SYNTH) {
+            if (synth) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * it + ((n16 + 4 * r) & 15);
+                        kv[jt][r] = (synth == 2 && i == 16 * jt + jj0) ? 1.0 : 0.0;
+                    }
+                return;
+            }
+        }
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * it + ((n16 + 4 * r) & 15);
-                if constexpr (SYNTH) {
-                    if (synth) {
-                        kv[jt][r] = (synth == 2 && i == 16 * jt + jj0) ? 1.0 : 0.0;
-                        continue;
-                    }
-                }
                 kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
             }
     };
