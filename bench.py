@@ -162,6 +162,18 @@ class TracingEngine:
         self._note("logml_grad", len(t), ka.n)
         return self._e.logml_grad_flat(ka, t, y)
 
+    def stage_grad(self, ka, t, y):
+        outer, job, n = self, self._e.stage_grad(ka, t, y), len(t)
+
+        class _CountedJob:      # every run of the resident job is one logml + gradient evaluation
+            def run(self, ka_now=None):
+                outer._note("logml_grad", n, ka.n)
+                return job.run(ka_now)
+
+            def close(self):
+                job.close()
+        return _CountedJob()
+
     def predict(self, programs, t, y, t_new, noise_on_new=True):
         self._note("predict", len(t), len(programs))
         return self._e.predict(programs, t, y, t_new, noise_on_new)
@@ -508,9 +520,12 @@ def main():
         if grad_mode:
             from nowcastautogp_amd._abi import KernelArray
             ka = KernelArray(progs)
+            gjob = ctx.stage_grad(ka, tt, Y)                      # inputs now resident in HBM
 
             def step():
-                lm, g, info = ctx.logml_grad_flat(ka, tt, Y)
+                # what a leapfrog step does: the parameters (the same ones here) go up again,
+                # nothing else crosses the bus but the results
+                lm, g, info = gjob.run(ka)
                 return {"info": info, "logml_full": lm, "grad": g}, None
         else:
             if precision == "mixed":
@@ -720,8 +735,9 @@ def main():
                                        f"{evals_per_item - 2} leapfrog(s)) per step: lockstep calls of "
                                        f"{B} items per GPU" if sharded else
                                        "every item its own kernel parameters (no dedupe)")
-                                    + ("; step = ONE logml + gradient call (inputs cross PCIe "
-                                       "inside the call: there is no staged gradient job)"
+                                    + ("; step = ONE run of a resident logml + gradient job "
+                                       "(ngp_grad_stage: trees, dates, observations staged before the timed "
+                                       "region; per step the parameters go up and the results come back)"
                                        if grad_mode else "")),
                        "items_per_gpu": B,
                        "parallelism": f"particles sharded x{world}" if sharded

@@ -191,6 +191,23 @@ ngp_status ngp_logml_grad_batch(ngp_ctx *ctx, int32_t B, const ngp_kernel *kerne
                                 int32_t n, const double *t, const double *y, int64_t ldy,
                                 double *logml, double *grad, int32_t *info);
 
+/* The same evaluation with its inputs resident on the device: trees, dates and observations are
+ * staged once (ngp_grad_stage: exactly ngp_logml_grad_batch's arguments), every
+ * ngp_grad_job_run evaluates logml and gradient for the parameters the job currently holds, and
+ * ngp_grad_job_set_params replaces them between runs — `params`: the items' parameter vectors
+ * back to back in the caller's (RPN) order, n_params_b each; noise[B].  The leapfrog steps of
+ * one HMC move (src/forecasting.jl:65,148; src/make_and_fit_model.jl:91) change nothing but the
+ * parameters: per step only they cross the bus (1 KiB per item instead of the observations and
+ * the compiled trees).  ngp_logml_grad_batch = stage + run + destroy; a run's outputs are those
+ * of the one-shot call, bit for bit.  The job keeps the spec it was staged under; it holds only
+ * its inputs and results between runs (the factor storage is taken per run).                  */
+typedef struct ngp_grad_job ngp_grad_job;
+ngp_status ngp_grad_stage(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels, int32_t n,
+                          const double *t, const double *y, int64_t ldy, ngp_grad_job **out);
+ngp_status ngp_grad_job_set_params(ngp_grad_job *job, const double *params, const double *noise);
+ngp_status ngp_grad_job_run(ngp_grad_job *job, double *logml, double *grad, int32_t *info);
+void       ngp_grad_job_destroy(ngp_grad_job *job);
+
 /* ---- particle weights -----------------------------------------------------
  * maybe_resample! arithmetic (src/forecasting.jl:138-141): normalise P
  * log-weights (logsumexp), effective sample size 1 / sum w^2.  In a multi-GPU

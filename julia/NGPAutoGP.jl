@@ -123,6 +123,57 @@ function logml_grad_batch(c::Context, progs::Vector{Program}, t::Vector{Float64}
     return lm, [grad[offs[i]+1:offs[i+1]] for i in 1:B], info
 end
 
+"""
+A gradient job whose trees, dates and observations stay on the device (include/ngp.h
+`ngp_grad_stage`): the leapfrog steps of one HMC move change nothing but the parameters, so per
+step only they cross the bus.  `run!(job, progs)` evaluates logml and gradient for the parameters
+`progs` hold now (the same trees, in the same order); `close(job)` releases it.
+"""
+mutable struct GradJob
+    h::Ptr{Cvoid}
+    sizes::Vector{Int}
+end
+
+function grad_stage(c::Context, progs::Vector{Program}, t::Vector{Float64}, y::VecOrMat{Float64})
+    B, n = length(progs), length(t)
+    ldy = y isa Vector ? 0 : n
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve progs begin
+        ks = kernels(progs)
+        check(ccall((:ngp_grad_stage, LIBNGP), Int32,
+                    (Ptr{Cvoid}, Int32, Ptr{NgpKernel}, Int32, Ptr{Float64}, Ptr{Float64}, Int64,
+                     Ptr{Ptr{Cvoid}}),
+                    c.h, B, ks, n, t, y, ldy, h), "ngp_grad_stage")
+    end
+    job = GradJob(h[], [length(p.params) + 1 for p in progs])
+    finalizer(close, job)
+    return job
+end
+
+function run!(job::GradJob, progs::Union{Nothing,Vector{Program}} = nothing)
+    B = length(job.sizes)
+    if progs !== nothing
+        flat = reduce(vcat, [p.params for p in progs]; init = Float64[])
+        noise = Float64[p.noise for p in progs]
+        check(ccall((:ngp_grad_job_set_params, LIBNGP), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
+                    job.h, flat, noise), "ngp_grad_job_set_params")
+    end
+    grad = Vector{Float64}(undef, sum(job.sizes))
+    lm, info = Vector{Float64}(undef, B), zeros(Int32, B)
+    check(ccall((:ngp_grad_job_run, LIBNGP), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                job.h, lm, grad, info), "ngp_grad_job_run")
+    offs = cumsum([0; job.sizes])
+    return lm, [grad[offs[i]+1:offs[i+1]] for i in 1:B], info
+end
+
+function Base.close(job::GradJob)
+    if job.h != C_NULL
+        ccall((:ngp_grad_job_destroy, LIBNGP), Cvoid, (Ptr{Cvoid},), job.h)
+        job.h = C_NULL
+    end
+    return nothing
+end
+
 function predict_batch(c::Context, progs::Vector{Program}, t::Vector{Float64},
                        y::VecOrMat{Float64}, t_new::Vector{Float64}; noise_on_new::Bool = true)
     B, n, m = length(progs), length(t), length(t_new)
@@ -553,6 +604,7 @@ function _hmc_move!(ms::Vector{GPModel}, t, ys, n_leapfrog::Int, eps::Float64)
     kinds = [vcat(param_kinds(p), [:wildcard]) for p in parts]
     z0 = [[untransform(th, k, prior) for (th, k) in zip(vcat(p.params, p.noise), kd)]
           for (p, kd) in zip(parts, kinds)]
+    job = nothing      # staged at the first evaluation: trees, dates, observations go up once per move
     function potential(z)
         progs = Program[]; dths = Vector{Float64}[]
         for (p, kd, zk) in zip(parts, kinds, z)
@@ -561,7 +613,12 @@ function _hmc_move!(ms::Vector{GPModel}, t, ys, n_leapfrog::Int, eps::Float64)
             push!(dths, [a[2] for a in td])
             push!(progs, Program(p.ops, th[1:end-1], max(th[end], 1.0e-12)))
         end
-        lm, grads, info = logml_grad_batch(ms[1].ctx, progs, t, Y)    # ONE call of P x D items
+        if job === nothing
+            job = grad_stage(ms[1].ctx, progs, t, Y)
+            lm, grads, info = run!(job)                                # ONE call of P x D items
+        else
+            lm, grads, info = run!(job, progs)                         # new parameters, nothing else
+        end
         U = similar(lm); dU = Vector{Float64}[]
         for i in 1:B
             ok = info[i] == 0 && isfinite(lm[i]) && all(isfinite, grads[i])
@@ -585,6 +642,7 @@ function _hmc_move!(ms::Vector{GPModel}, t, ys, n_leapfrog::Int, eps::Float64)
         h = step < n_leapfrog ? eps : 0.5 * eps
         pm = [pm[i] .- h .* dU[i] for i in 1:B]
     end
+    job === nothing || close(job)
     acc = 0
     for (i, (j, k)) in enumerate(items)
         H1 = U1[i] + 0.5 * sum(abs2, pm[i])

@@ -26,7 +26,8 @@ KERNEL_CLASSES = ("chol_col", "chol_diag", "gram", "epilogue", "fill", "grad_kin
 SYMBOLS = (
     "ngp_ctx_create", "ngp_ctx_destroy", "ngp_set_spec", "ngp_get_spec", "ngp_default_spec",
     "ngp_strerror", "ngp_version", "ngp_kernel_check", "ngp_cov_batch", "ngp_logml_batch",
-    "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_weights_normalize",
+    "ngp_predict_batch", "ngp_nowcast_batch", "ngp_logml_grad_batch", "ngp_grad_stage",
+    "ngp_grad_job_set_params", "ngp_grad_job_run", "ngp_grad_job_destroy", "ngp_weights_normalize",
     "ngp_weights_normalize_cols", "ngp_mixture_sample_indep", "ngp_shard", "ngp_comm_unique_id", "ngp_comm_create",
     "ngp_comm_destroy", "ngp_weights_allgather_normalize",
     "ngp_logml_stage", "ngp_predict_stage", "ngp_nowcast_stage", "ngp_job_run", "ngp_job_fetch",
@@ -83,6 +84,10 @@ def load():
         "ngp_nowcast_batch": (i32, [vp, i32, KP, i32, f64p, f64p, i32, f64p, i32, f64p, i32, f64p,
                                     i32, f64p, f64p, f64p, f64p, i32p]),
         "ngp_logml_grad_batch": (i32, [vp, i32, KP, i32, f64p, f64p, i64, f64p, f64p, i32p]),
+        "ngp_grad_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, C.POINTER(vp)]),
+        "ngp_grad_job_set_params": (i32, [vp, f64p, f64p]),
+        "ngp_grad_job_run": (i32, [vp, f64p, f64p, i32p]),
+        "ngp_grad_job_destroy": (None, [vp]),
         "ngp_weights_normalize": (i32, [i32, f64p, f64p, f64p, f64p]),
         "ngp_weights_normalize_cols": (i32, [i32, i32, f64p, f64p, f64p, f64p]),
         "ngp_mixture_sample_indep": (i32, [vp, i32, i32, i32, f64p, f64p, f64p, i32,
@@ -220,6 +225,41 @@ class Comm:
 
 def _nullable(a: Optional[np.ndarray]):
     return dptr(a) if a is not None else None
+
+
+class GradJob:
+    """A gradient job whose trees, dates and observations stay on the device (``ngp_grad_stage``):
+    ``run(ka)`` evaluates logml and gradient for the parameters ``ka`` holds NOW (the same trees —
+    ``KernelArray.set_params`` between runs), sending nothing else across the bus."""
+
+    def __init__(self, ctx: "Context", handle, ka: KernelArray):
+        self._ctx, self._h, self.n = ctx, handle, ka.n
+        ctx._children.add(self)          # closed with the context if still open (it holds a ctx pointer)
+        self._ngrad = int(ka._npar.sum()) + ka.n
+
+    def run(self, ka: Optional[KernelArray] = None):
+        L = load()
+        if ka is not None:
+            if ka.n != self.n or int(ka._npar.sum()) + ka.n != self._ngrad:
+                raise ValueError("GradJob.run: the kernel array must hold the staged trees")
+            noise = np.ascontiguousarray(ka._rec["noise"][:ka.n])
+            _chk(L.ngp_grad_job_set_params(self._h, dptr(ka._params), dptr(noise)),
+                 "ngp_grad_job_set_params")
+        grad = np.empty(self._ngrad)
+        lm, info = np.empty(self.n), np.zeros(self.n, dtype=np.int32)
+        _chk(L.ngp_grad_job_run(self._h, dptr(lm), dptr(grad), iptr(info)), "ngp_grad_job_run")
+        return lm, grad, info
+
+    def close(self):
+        if self._h:
+            load().ngp_grad_job_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Job:
@@ -465,6 +505,15 @@ class Context:
                                          dptr(lm), dptr(grad), iptr(info)),
              "ngp_logml_grad_batch")
         return lm, grad, info
+
+    def stage_grad(self, ka: KernelArray, t, y) -> GradJob:
+        """``ngp_grad_stage``: the inputs of ``logml_grad_flat`` made resident; see GradJob."""
+        t = as_f64(t)
+        y, ldy = self._ymat(y, ka.n, t.size)
+        h = C.c_void_p()
+        _chk(load().ngp_grad_stage(self._h, ka.n, ka.arr, t.size, dptr(t), dptr(y), ldy,
+                                   C.byref(h)), "ngp_grad_stage")
+        return GradJob(self, h, ka)
 
     def logml_grad_batch(self, programs, t, y):
         ka = KernelArray(programs)

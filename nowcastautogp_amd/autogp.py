@@ -64,6 +64,10 @@ class HipEngine:
         from ._abi import KernelArray
         return KernelArray(programs)
 
+    def stage_grad(self, ka, t, y):
+        """the inputs of ``logml_grad_flat`` resident on the device for several evaluations"""
+        return self.ctx.stage_grad(ka, t, y)
+
     def logml_grad_flat(self, ka, t, y):
         return self.ctx.logml_grad_flat(ka, t, y)
 
@@ -593,9 +597,13 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
     eng = models[0]._eng()
     if Y is None:     # the callers that make several moves on the same data pass it in
         Y = _item_y(ys, [j for j, _ in items])
-    ka = None
+    ka = job = None
     if hasattr(eng, "logml_grad_flat"):
         ka = eng.kernel_array([(ops[i], np.zeros(sizes[i] - 1), 0.0) for i in range(B)])
+        # the leapfrog steps change nothing but the parameters: trees, dates and observations are
+        # staged once per move (include/ngp.h ngp_grad_stage), each evaluation sends the parameters
+        if hasattr(eng, "stage_grad"):
+            job = eng.stage_grad(ka, t, Y)
 
     def sums(v):                                             # per-item sums of a flat vector
         return np.bincount(seg, weights=v, minlength=B)
@@ -614,7 +622,7 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
             th[i_unit] = np.clip(th[i_unit], 1e-9, 1.0 - 1e-9)
         if ka is not None:      # same structures, new parameters: refill the C array in place
             ka.set_params(th[i_param], th[last])
-            lm, g, info = eng.logml_grad_flat(ka, t, Y)
+            lm, g, info = job.run(ka) if job is not None else eng.logml_grad_flat(ka, t, Y)
         else:
             progs = [(ops[i], th[sl[i]][:-1], float(th[last[i]])) for i in range(B)]
             lm, grads, info = eng.logml_grad(progs, t, Y)
@@ -639,6 +647,8 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
         z = z + eps * pm
         U1, dU, lm1 = potential(z)
         pm = pm - (eps if step < n_leapfrog - 1 else 0.5 * eps) * dU
+    if job is not None:
+        job.close()
     with np.errstate(invalid="ignore", over="ignore"):
         H1 = U1 + 0.5 * sums(pm * pm)
     th_new, _ = to_theta(z)

@@ -5,8 +5,10 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "ngp_internal.h"
@@ -1667,25 +1669,55 @@ extern "C" ngp_status ngp_cov_batch(ngp_ctx *c, int32_t B, const ngp_kernel *ker
     return e == hipSuccess ? NGP_OK : (ngp_status)e;
 }
 
-extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kernel *kernels,
-                                           int32_t n, const double *t, const double *y,
-                                           int64_t ldy, double *logml, double *grad,
-                                           int32_t *info) {
-    if (!c || !kernels || !t || !y || !grad || B <= 0 || n <= 0) return NGP_ERR_ARG;
-    std::vector<DevProgram> hp((size_t)B);
-    std::vector<std::vector<int>> perm((size_t)B);
+// ---------------------------------------------------------------------------------------
+// gradient jobs: the inputs of ngp_logml_grad_batch kept on the device across calls
+// ---------------------------------------------------------------------------------------
+struct ngp_grad_job {
+    ngp_ctx *ctx = nullptr;
+    JobGeom g{};
+    int B = 0, n = 0;
+    std::vector<DevProgram> hp;            // compiled programs (device parameter order)
+    std::vector<std::vector<int>> perm;    // device parameter k of item i = the caller's perm[i][k]
+    std::vector<int32_t> n_ops, n_params;
+    // ONE device arena for everything that crosses the bus:
+    //   [programs | t | y | lattice indices | info | logdet | gradient | logml]
+    unsigned char *io = nullptr;
+    size_t o_t = 0, o_y = 0, o_q = 0, o_info = 0, o_logdet = 0, o_grad = 0, o_logml = 0, io_bytes = 0;
+    std::vector<unsigned char> h_in, h_out;   // staging copy of a small job's inputs; results
+    bool fresh = false;                    // info / logdet still hold the zeros they were staged with
+    bool progs_dirty = false;              // set_params since the last upload
+    ngp_spec spec{};
+};
+
+extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
+                                     const double *t, const double *y, int64_t ldy,
+                                     ngp_grad_job **out) {
+    if (!c || !out || !kernels || !t || !y || B <= 0 || n <= 0) return NGP_ERR_ARG;
+    *out = nullptr;
+    ngp_grad_job *j = new (std::nothrow) ngp_grad_job();
+    if (!j) return NGP_ERR_TOO_LARGE;
+    std::unique_ptr<ngp_grad_job> guard(j);
+    j->ctx = c;
+    j->B = B;
+    j->n = n;
+    j->hp.resize((size_t)B);
+    j->perm.resize((size_t)B);
+    j->n_ops.resize((size_t)B);
+    j->n_params.resize((size_t)B);
     int maxstat = 0, maxcp = 0, maxops = 0;
     for (int i = 0; i < B; ++i) {
         int ns = 0, nc = 0;
-        ngp_status st = compile_program(&kernels[i], &hp[(size_t)i], &perm[(size_t)i], &ns, &nc);
+        ngp_status st = compile_program(&kernels[i], &j->hp[(size_t)i], &j->perm[(size_t)i], &ns, &nc);
         if (st) return st;
         maxstat = std::max(maxstat, ns);
         maxcp = std::max(maxcp, nc);
         maxops = std::max(maxops, (int)kernels[i].n_ops);
+        j->n_ops[(size_t)i] = kernels[i].n_ops;
+        j->n_params[(size_t)i] = kernels[i].n_params;
     }
     // Geometry: the matrix is padded to a multiple of 64 with identity rows/cols (log 1 = 0, a
     // zero in y), and the aux block is [I ; y'] so that the factorisation leaves W = [L^-T ; z'].
-    JobGeom g{};
+    JobGeom &g = j->g;
     g.B = B;
     g.n0 = (n + NB - 1) / NB * NB;
     g.nb0 = g.n0 / NB;
@@ -1716,31 +1748,81 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     }
     const int ny = g.y_shared ? 1 : B;
     const int GP = NGP_MAX_PARAMS + 1;
-    // ONE device arena for everything that crosses the bus: [programs | t | y | lattice indices |
-    // info | logdet | gradient | logml].  The front part goes up in one copy (info and logdet
-    // arrive as the zeros the factorisation expects), the tail comes back in one: a 24-particle
-    // call of a fit on a short series is a chain of dependent launches a few microseconds long,
-    // and each separate copy or memset was one more of them.
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_t = al(sizeof(DevProgram) * (size_t)B), o_y = o_t + al(8 * (size_t)g.n0),
-                 o_q = o_y + al(8 * (size_t)ny * g.n0),
-                 o_info = o_q + (g.lattice ? al(4 * (size_t)g.n0) : 0),
-                 o_logdet = o_info + al(4 * (size_t)B), o_grad = o_logdet + al(8 * (size_t)B),
-                 o_logml = o_grad + al(8 * (size_t)B * GP), io_bytes = o_logml + al(8 * (size_t)B);
-    std::vector<unsigned char> h_in(o_grad, 0), h_out(io_bytes - o_info);
-    std::memcpy(h_in.data(), hp.data(), sizeof(DevProgram) * (size_t)B);
+    j->o_t = al(sizeof(DevProgram) * (size_t)B);
+    j->o_y = j->o_t + al(8 * (size_t)g.n0);
+    j->o_q = j->o_y + al(8 * (size_t)ny * g.n0);
+    j->o_info = j->o_q + (g.lattice ? al(4 * (size_t)g.n0) : 0);
+    j->o_logdet = j->o_info + al(4 * (size_t)B);
+    j->o_grad = j->o_logdet + al(8 * (size_t)B);
+    j->o_logml = j->o_grad + al(8 * (size_t)B * GP);
+    j->io_bytes = j->o_logml + al(8 * (size_t)B);
+    j->h_in.assign(j->o_grad, 0);
+    j->h_out.resize(j->io_bytes - j->o_info);
+    std::memcpy(j->h_in.data(), j->hp.data(), sizeof(DevProgram) * (size_t)B);
     {
-        double *ht = (double *)(h_in.data() + o_t), *hy = (double *)(h_in.data() + o_y);
+        double *ht = (double *)(j->h_in.data() + j->o_t), *hy = (double *)(j->h_in.data() + j->o_y);
         for (int i = 0; i < g.n0; ++i) ht[i] = t[std::min(i, n - 1)];
         for (int b = 0; b < ny; ++b)
             for (int i = 0; i < n; ++i) hy[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
-        if (g.lattice) std::memcpy(h_in.data() + o_q, h_q.data(), 4 * (size_t)g.n0);
+        if (g.lattice) std::memcpy(j->h_in.data() + j->o_q, h_q.data(), 4 * (size_t)g.n0);
     }
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    j->spec = c->spec;
+    void *q = nullptr;
+    ngp_status st = c->alloc(&q, j->io_bytes);
+    if (st) return st;
+    j->io = (unsigned char *)q;
+    // the front part goes up in one copy (info and logdet arrive as the zeros the factorisation
+    // expects): a 24-particle call of a fit on a short series is a chain of dependent launches a
+    // few microseconds long, and each separate copy or memset was one more of them
+    if (hipMemcpyAsync(j->io, j->h_in.data(), j->h_in.size(), hipMemcpyHostToDevice, c->stream) !=
+        hipSuccess) {
+        c->release(j->io);
+        return NGP_ERR_STATE;
+    }
+    j->fresh = true;
+    // a small staging buffer stays with the job (the run is queued right behind the copy); a
+    // large one is given back once the copy has left it
+    if (j->h_in.size() > STAGE_KEEP_BYTES) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess) {
+            c->release(j->io);
+            return NGP_ERR_STATE;
+        }
+        std::vector<unsigned char>().swap(j->h_in);
+    }
+    *out = guard.release();
+    return NGP_OK;
+}
 
+extern "C" ngp_status ngp_grad_job_set_params(ngp_grad_job *j, const double *params,
+                                              const double *noise) {
+    if (!j || !params || !noise) return NGP_ERR_ARG;
+    size_t off = 0;
+    for (int i = 0; i < j->B; ++i) {
+        DevProgram &P = j->hp[(size_t)i];
+        const int np = j->n_params[(size_t)i];
+        // values are taken as ngp_logml_grad_batch takes them: a parameter the kernels cannot use
+        // shows in the item's info, not here
+        for (int q = 0; q < np; ++q) P.params[q] = params[off + (size_t)j->perm[(size_t)i][(size_t)q]];
+        P.noise = noise[i];
+        off += (size_t)np;
+    }
+    j->progs_dirty = true;
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *grad, int32_t *info) {
+    if (!j || !grad) return NGP_ERR_ARG;
+    ngp_ctx *c = j->ctx;
+    const JobGeom &g = j->g;
+    const int B = j->B;
+    const int GP = NGP_MAX_PARAMS + 1;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const DevSpec sp = dev_spec(c->spec);
+    const DevSpec sp = dev_spec(j->spec);
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
     std::vector<void *> owned;
     auto freeall = [&] { for (void *q : owned) c->release(q); };
@@ -1757,13 +1839,13 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
     if ((size_t)B * item_bytes > c->mem_cap) c->refresh_mem_cap();   // large job: today's figure
     int Bc = (int)std::min<size_t>(std::min<size_t>((size_t)B, MAX_CHUNK_ITEMS),
                                    std::max<size_t>(1, c->mem_cap / item_bytes));
-    void *d_io, *d_L, *d_dinv, *d_tab = nullptr, *d_sig = nullptr, *d_dtab = nullptr, *d_kinv,
+    void *d_L, *d_dinv, *d_tab = nullptr, *d_sig = nullptr, *d_dtab = nullptr, *d_kinv,
          *d_alpha, *d_quad, *d_part, *d_items;
     std::vector<int32_t> h_items((size_t)B);   // alive until the stream is synchronised below
     ngp_status st;
     // the chunk is halved when the device cannot hold it after all (other handles, rounding)
     for (;; Bc = (Bc + 1) / 2) {
-        if (!((st = dalloc(&d_io, io_bytes)) || (st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
+        if (!((st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
               (st = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
               (g.lattice && ((st = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
                              (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)) ||
@@ -1781,13 +1863,20 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         owned.clear();
         if (st != NGP_ERR_TOO_LARGE || Bc <= 1) return st;
     }
-    unsigned char *const io = (unsigned char *)d_io;
-    void *const d_prog = io, *const d_t = io + o_t, *const d_y = io + o_y,
-                *const d_q = g.lattice ? io + o_q : nullptr, *const d_info = io + o_info,
-                *const d_logdet = io + o_logdet, *const d_grad = io + o_grad,
-                *const d_logml = io + o_logml;
-    hipError_t e = hipMemcpyAsync(d_io, h_in.data(), h_in.size(), hipMemcpyHostToDevice, s);
+    unsigned char *const io = j->io;
+    void *const d_prog = io, *const d_t = io + j->o_t, *const d_y = io + j->o_y,
+                *const d_q = g.lattice ? io + j->o_q : nullptr, *const d_info = io + j->o_info,
+                *const d_logdet = io + j->o_logdet, *const d_grad = io + j->o_grad,
+                *const d_logml = io + j->o_logml;
+    hipError_t e = hipSuccess;
+    if (j->progs_dirty)   // new parameters for the same trees: the programs go up again, nothing else
+        e = hipMemcpyAsync(d_prog, j->hp.data(), sizeof(DevProgram) * (size_t)B,
+                           hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && !j->fresh)   // a re-run: info | logdet are contiguous in the arena
+        e = hipMemsetAsync(d_info, 0, j->o_grad - j->o_info, s);
     if (e != hipSuccess) { freeall(); return (ngp_status)e; }
+    j->progs_dirty = false;
+    j->fresh = false;
     EventTimer tm(c->profiling, s);
     for (int b0 = 0; b0 < B; b0 += Bc) {
         const int bc = std::min(Bc, B - b0);
@@ -1823,11 +1912,11 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
         const bool by_size = g.lattice && (long)ntri * bc > 4096;
         int32_t counts[GRAD_BUCKETS] = {};
         if (by_size) {
-            for (int i = 0; i < bc; ++i) ++counts[grad_bucket(kernels[b0 + i].n_ops)];
+            for (int i = 0; i < bc; ++i) ++counts[grad_bucket(j->n_ops[(size_t)(b0 + i)])];
             int32_t pos[GRAD_BUCKETS], acc = 0;
             for (int k = 0; k < GRAD_BUCKETS; ++k) { pos[k] = acc; acc += counts[k]; }
             for (int i = 0; i < bc; ++i)
-                h_items[(size_t)b0 + (size_t)pos[grad_bucket(kernels[b0 + i].n_ops)]++] = i;
+                h_items[(size_t)b0 + (size_t)pos[grad_bucket(j->n_ops[(size_t)(b0 + i)])]++] = i;
             const hipError_t ce = hipMemcpyAsync((int32_t *)d_items + b0, h_items.data() + b0,
                                                  4 * (size_t)bc, hipMemcpyHostToDevice, s);
             if (ce != hipSuccess) {
@@ -1845,27 +1934,53 @@ extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kern
                                  c->side, c->ev_fork, c->ev_join);
         });
     }
-    e = hipMemcpyAsync(h_out.data(), d_info, h_out.size(), hipMemcpyDeviceToHost, s);
+    e = hipMemcpyAsync(j->h_out.data(), d_info, j->h_out.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();
     tm.resolve(c->prof);
     freeall();
+    if (!j->h_in.empty()) std::vector<unsigned char>().swap(j->h_in);   // the staging copy has left it
     if (e != hipSuccess) return (ngp_status)e;
     // device parameter order -> caller's order; d/d noise last
-    const int32_t *h_info = (const int32_t *)h_out.data();
-    const double *h_grad = (const double *)(h_out.data() + (o_grad - o_info)),
-                 *h_lm = (const double *)(h_out.data() + (o_logml - o_info));
+    const int32_t *h_info = (const int32_t *)j->h_out.data();
+    const double *h_grad = (const double *)(j->h_out.data() + (j->o_grad - j->o_info)),
+                 *h_lm = (const double *)(j->h_out.data() + (j->o_logml - j->o_info));
     size_t off = 0;
     for (int i = 0; i < B; ++i) {
-        const int np = kernels[i].n_params;
+        const int np = j->n_params[(size_t)i];
         for (int k = 0; k < np; ++k)
-            grad[off + (size_t)perm[(size_t)i][(size_t)k]] = h_grad[(size_t)i * GP + (size_t)k];
+            grad[off + (size_t)j->perm[(size_t)i][(size_t)k]] = h_grad[(size_t)i * GP + (size_t)k];
         grad[off + (size_t)np] = h_grad[(size_t)i * GP + (size_t)np];
         off += (size_t)np + 1;
         if (logml) logml[i] = h_lm[(size_t)i];
         if (info) info[i] = h_info[(size_t)i];
     }
     return NGP_OK;
+}
+
+extern "C" void ngp_grad_job_destroy(ngp_grad_job *j) {
+    if (!j) return;
+    {
+        std::lock_guard<std::mutex> lk(j->ctx->mu);
+        (void)hipSetDevice(j->ctx->device);
+        // a staging buffer that was kept must outlive its copy
+        if (!j->h_in.empty()) (void)hipStreamSynchronize(j->ctx->stream);
+        j->ctx->release(j->io);
+    }
+    delete j;
+}
+
+extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kernel *kernels,
+                                           int32_t n, const double *t, const double *y,
+                                           int64_t ldy, double *logml, double *grad,
+                                           int32_t *info) {
+    if (!grad) return NGP_ERR_ARG;
+    ngp_grad_job *j = nullptr;
+    ngp_status st = ngp_grad_stage(c, B, kernels, n, t, y, ldy, &j);
+    if (st) return st;
+    st = ngp_grad_job_run(j, logml, grad, info);
+    ngp_grad_job_destroy(j);
+    return st;
 }
 
 // one column of a [P x ld]-strided log-weight matrix (ld = 1: a plain vector)
@@ -1996,8 +2111,26 @@ struct RcclApi {
 };
 RcclApi load_rccl() {
     RcclApi r;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // The RCCL that belongs to the HIP runtime THIS library is bound to, by path: a host process may
+    // hold a second ROCm stack (PyTorch wheels bundle libamdhip64 / libhsa-runtime64 / librccl; when
+    // torch is imported after libngp both stacks are mapped), and a bare dlopen("librccl.so.1")
+    // then returns the copy already loaded — tied to the other, uninitialised runtime
+    // ("no ROCm-capable device", scripts/rccl_probe.py).  The directory of the libamdhip64 that
+    // resolved our own HIP calls decides.
+    std::vector<std::string> names;
+    Dl_info di{};
+    if (dladdr((void *)&hipGetDeviceCount, &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            names.push_back(dir + "librccl.so.1");
+            names.push_back(dir + "librccl.so");
+        }
+    }
+    for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) names.push_back(nm);
+    for (const std::string &name : names) {
+        r.handle = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
     }
     if (!r.handle) return r;
@@ -2044,9 +2177,19 @@ extern "C" ngp_status ngp_comm_create(ngp_ctx *c, const void *id128, int32_t ran
     m->ctx = c;
     m->rank = rank;
     m->world = world;
+    // RCCL allocates its own device buffers: after a large job most of the device can sit in the
+    // caching allocators of this process, so a failed initialisation is tried once more with the
+    // caches given back
     if (rccl().CommInitRank(&m->comm, world, uid, rank) != 0) {
-        delete m;
-        return NGP_ERR_UNAVAILABLE;
+        (void)hipGetLastError();
+        c->drop_cache();
+        ngp_ctx::drop_other_caches(c);
+        m->comm = nullptr;
+        if (rccl().CommInitRank(&m->comm, world, uid, rank) != 0) {
+            (void)hipGetLastError();
+            delete m;
+            return NGP_ERR_UNAVAILABLE;
+        }
     }
     *out = m;
     return NGP_OK;

@@ -68,6 +68,22 @@ static void worker(ngp_ctx *ctx, int id, int rounds) {
                   "job_fetch");
             ngp_job_destroy(job);
         }
+        // resident gradient job: run, new parameters, run again, destroy; and the storage option
+        ngp_grad_job *gj = nullptr;
+        CHECK(ngp_grad_stage(ctx, P, e.ks, n, t.data(), y.data(), 0, &gj) == NGP_OK && gj, "grad_stage");
+        if (gj) {
+            CHECK(ngp_grad_job_run(gj, lm.data(), grad.data(), info.data()) == NGP_OK, "grad_job_run");
+            std::vector<double> flat, nz;
+            for (int k = 0; k < P; ++k) {
+                for (int q = 0; q < e.ks[k].n_params; ++q) flat.push_back(e.ks[k].params[q] * 1.01);
+                nz.push_back(e.ks[k].noise * 0.9);
+            }
+            CHECK(ngp_grad_job_set_params(gj, flat.data(), nz.data()) == NGP_OK, "grad_job_set_params");
+            CHECK(ngp_grad_job_run(gj, nullptr, grad.data(), nullptr) == NGP_OK, "grad_job_run again");
+            CHECK(ngp_grad_job_set_params(gj, nullptr, nz.data()) != NGP_OK, "null parameters accepted");
+            ngp_grad_job_destroy(gj);
+        }
+        CHECK(ngp_set_structured_storage(ctx, (r + id) & 1) == NGP_OK, "set_structured_storage");
         // resident factor
         ngp_factor *f = nullptr;
         CHECK(ngp_factor_create(ctx, P, e.ks, n, t.data(), y.data(), 0, &f) == NGP_OK && f, "factor_create");

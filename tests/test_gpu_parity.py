@@ -765,3 +765,38 @@ def test_kernel_array_refill_and_flat_gradient(ctx):
         rlm, rg, rinfo = ctx.logml_grad_batch(progs, w.t, w.y)
         assert not info.any() and not rinfo.any()
         assert np.array_equal(lm, rlm) and np.array_equal(g, np.concatenate(rg))
+
+
+def test_resident_gradient_job_equals_the_one_shot_call(ctx):
+    """ngp_grad_stage / ngp_grad_job_set_params / ngp_grad_job_run (the leapfrog steps of one HMC
+    move: same trees, new parameters): every run's outputs are the one-shot call's, bit for bit —
+    short and long series, shared y and per-item y rows, a re-run without new parameters, and a
+    parameter set that makes one item's matrix indefinite (reported in info, the others intact)."""
+    from nowcastautogp_amd._abi import KernelArray
+    rng = np.random.Generator(np.random.PCG64(11))
+    for n, P, per_item in ((150, 5, False), (208, 24, True), (705, 7, True), (1600, 64, False)):
+        w = make_workload("C2", n=n, P=P, D=1)
+        y = w.y[None, :] + 0.02 * rng.standard_normal((P, n)) if per_item else w.y
+        ka = KernelArray(list(w.programs))
+        job = ctx.stage_grad(ka, w.t, y)
+        lm, g, info = job.run()                      # the parameters it was staged with
+        rlm, rg, rinfo = ctx.logml_grad_flat(ka, w.t, y)
+        assert np.array_equal(lm, rlm) and np.array_equal(g, rg) and np.array_equal(info, rinfo)
+        for it in range(3):
+            progs = [(ops, params * np.exp(0.05 * rng.standard_normal(len(params))), noise * 1.07)
+                     for ops, params, noise in w.programs]
+            if it == 2:      # a negative amplitude / noise: that item fails, and only that one
+                ops0, p0, _ = progs[0]
+                progs[0] = (ops0, p0, -1.0)
+            ka.set_params(np.concatenate([p[1] for p in progs]), np.array([p[2] for p in progs]))
+            lm, g, info = job.run(ka)
+            rlm, rg, rinfo = ctx.logml_grad_batch(progs, w.t, y)
+            assert np.array_equal(info, rinfo)
+            ok = info == 0
+            assert ok[1:].all() and (it < 2 or not ok[0])
+            offs = np.concatenate([[0], np.cumsum(ka._npar + 1)])
+            for b in np.flatnonzero(ok):
+                assert lm[b] == rlm[b] and np.array_equal(g[offs[b]:offs[b + 1]], rg[b]), (n, it, b)
+            again = job.run()                        # nothing new: the same answer again
+            assert np.array_equal(again[0][ok], lm[ok]) and np.array_equal(again[2], info)
+        job.close()

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 JL = open(os.path.join(ROOT, "julia", "NGPAutoGP.jl"), encoding="utf-8").read()
 HDR = open(os.path.join(ROOT, "include", "ngp.h"), encoding="utf-8").read()
 
-HANDLES = ("ngp_ctx", "ngp_job", "ngp_factor", "ngp_comm")
+HANDLES = ("ngp_ctx", "ngp_job", "ngp_grad_job", "ngp_factor", "ngp_comm")
 STRUCTS = {"ngp_kernel": "NgpKernel", "ngp_spec": "NgpSpec", "ngp_profile": "NgpProfile"}
 SCALARS = {"int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64", "double": "Float64",
            "float": "Float32", "ngp_status": "Int32"}
@@ -189,7 +189,10 @@ def test_the_lockstep_ensemble_and_its_limits_are_there():
         assert multi + "([m]" in body, single
     # every leapfrog is ONE gradient call over all items, with per-item y rows
     hmc = re.search(r"function _hmc_move!\(ms::Vector\{GPModel\}.*?\nend\n", JL, re.S).group(0)
-    assert hmc.count("logml_grad_batch(") == 1 and "_item_y(ys" in hmc
+    # (since round 3 through a resident gradient job: staged once per move with all items, then one
+    # run per leapfrog that sends the parameters only)
+    assert hmc.count("grad_stage(ms[1].ctx, progs, t, Y)") == 1 and hmc.count("run!(job") == 2
+    assert "close(job)" in hmc and "_item_y(ys" in hmc
     assert "NGP_MAX_AUX = 192" in JL and "_check_horizon(length(t), length(dates))" in JL
     hdr_aux = int(re.search(r"#define NGP_MAX_AUX\s+(\d+)", HDR).group(1))
     assert hdr_aux == 192

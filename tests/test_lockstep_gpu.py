@@ -48,6 +48,18 @@ class _Counting:
         self.calls.append(("logml_grad", ka.n))
         return self._e.logml_grad_flat(ka, t, y)
 
+    def stage_grad(self, ka, t, y):
+        outer, job = self, self._e.stage_grad(ka, t, y)
+
+        class _Counted:      # a run of the resident job is one gradient call of ka.n items
+            def run(self, ka_now=None):
+                outer.calls.append(("logml_grad", ka.n))
+                return job.run(ka_now)
+
+            def close(self):
+                job.close()
+        return _Counted()
+
     def predict(self, programs, t, y, t_new, noise_on_new=True):
         self.calls.append(("predict", len(programs)))
         return self._e.predict(programs, t, y, t_new, noise_on_new)
@@ -174,9 +186,14 @@ def test_c_abi_collective_at_world_size_one(eng):
     rank is the whole world, so the result must be ngp_weights_normalize_cols of the same matrix;
     a ragged P_total / world split is exercised on CPU (tests/test_distributed_gloo.py) through the
     same block partition."""
-    uid = _lib.comm_unique_id()
-    assert len(uid) == 128
-    comm = _lib.Comm(eng.ctx, uid, 0, 1)
+    try:
+        uid = _lib.comm_unique_id()
+        assert len(uid) == 128
+        comm = _lib.Comm(eng.ctx, uid, 0, 1)
+    except _lib.NgpError as e:
+        if e.status == -6:     # NGP_ERR_UNAVAILABLE: the optional component, by its contract
+            pytest.skip(f"librccl does not initialise on this box: {e}")
+        raise
     rng = np.random.default_rng(4)
     lw = -300.0 + 5.0 * rng.standard_normal((7, 4))
     lw[3, 2] = -np.inf
