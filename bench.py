@@ -319,6 +319,9 @@ def fit_forecast_wallclock(w, device, rank, args):
            "fit_s": legs["fit_small_budget"]["gpu_s"],
            "forecast_with_nowcasts_s": legs["forecast_with_nowcasts_first"]["gpu_s"],
            "forecast_with_nowcasts_again_s": t_fc_again, "finite_and_shaped": ok, "legs": legs}
+    # the legs' context gives its device memory back (its workspace holds the largest leg's working
+    # storage): the legs of other_configs run as child processes and size their chunks by what is free
+    eng.ctx.close()
     if prices is None:
         res["cpu_estimate_error"] = err
         return res

@@ -298,6 +298,50 @@ struct ngp_ctx {
         free_blocks.clear();
         cached_bytes = 0;
     }
+    // Workspace: ONE grow-only block for the working storage of a call (factor slabs, K^-1, tables —
+    // everything a run takes at its start and gives back at its end; calls on a context are
+    // serialised and end synchronised, so the next call may overwrite it).  Jobs of different
+    // shapes alternate in the reference's flow — gradient calls (115 + 57 GB blocks at 12,800 items)
+    // and a predictive call (221 GB) in forecast_with_nowcasts' refinement modes — and with
+    // per-shape blocks every switch freed and re-allocated most of the device: 7.7 of the 8.5 s the
+    // predictive call of the lockstep HMC leg took (scripts/hmc_leg_cprofile.py).  Things that
+    // outlive a call (job arenas, resident factors) stay with alloc / release.
+    void *ws_base = nullptr;
+    size_t ws_cap = 0, ws_used = 0;
+    void ws_drop() {
+        if (ws_base) (void)hipFree(ws_base);
+        ws_base = nullptr;
+        ws_cap = ws_used = 0;
+    }
+    static size_t ws_round(size_t bytes) { return (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255; }
+    // room for `total` bytes of bump allocations (sum of ws_round of the pieces); the previous
+    // call's contents are dead
+    ngp_status ws_reserve(size_t total) {
+        ws_used = 0;
+        if (total <= ws_cap) return NGP_OK;
+        ws_drop();
+        hipError_t e = hipMalloc(&ws_base, total);
+        for (int attempt = 0; e != hipSuccess && attempt < 2; ++attempt) {
+            (void)hipGetLastError();   // handled here: must not surface as the job's last error
+            if (attempt == 0) drop_cache();
+            else drop_other_caches(this);
+            e = hipMalloc(&ws_base, total);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ws_base = nullptr;
+            return NGP_ERR_TOO_LARGE;
+        }
+        ws_cap = total;
+        return NGP_OK;
+    }
+    void *ws_take(size_t bytes) {   // inside the reservation: cannot fail
+        bytes = ws_round(bytes);
+        if (ws_used + bytes > ws_cap) return nullptr;
+        void *p = (char *)ws_base + ws_used;
+        ws_used += bytes;
+        return p;
+    }
     static void drop_other_caches(ngp_ctx *self);
     ngp_status alloc(void **p, size_t bytes) {
         bytes = (bytes + 255) / 256 * 256;
@@ -352,7 +396,7 @@ struct ngp_ctx {
     void refresh_mem_cap() {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess)
-            mem_cap = (size_t)(0.75 * (double)(fr + cached_bytes));
+            mem_cap = (size_t)(0.75 * (double)(fr + cached_bytes + ws_cap));
     }
 };
 
@@ -365,10 +409,28 @@ void ngp_ctx::drop_other_caches(ngp_ctx *self) {
         if (o == self || o->device != self->device) continue;
         if (o->mu.try_lock()) {   // a context in the middle of a call keeps its cache
             o->drop_cache();
+            o->ws_drop();
             o->mu.unlock();
         }
     }
 }
+
+// The working storage of a run is laid out twice through the same sequence of requests: once to
+// add the sizes up (the workspace is then reserved in one piece), once to take the pieces.
+struct WsPlan {
+    ngp_ctx *c;
+    bool measuring;
+    size_t total = 0;
+    ngp_status operator()(void **q, size_t bytes) {
+        if (measuring) {
+            total += ngp_ctx::ws_round(bytes);
+            *q = nullptr;
+            return NGP_OK;
+        }
+        *q = c->ws_take(bytes);
+        return *q ? NGP_OK : NGP_ERR_TOO_LARGE;
+    }
+};
 
 static DevSpec dev_spec(const ngp_spec &s) {
     return DevSpec{s.se_form, s.periodic_form, s.cp_form, s.precision, s.jitter, s.mixed_tau};
@@ -453,6 +515,7 @@ extern "C" void ngp_ctx_destroy(ngp_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto &kv : c->free_blocks) (void)hipFree(kv.second);
     for (auto &kv : c->live) (void)hipFree(kv.first);
+    c->ws_drop();
     (void)hipStreamDestroy(c->stream);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1082,16 +1145,8 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     j->refine_steps.assign((size_t)g.B, 0);
     j->refine_delta.assign((size_t)g.B, 0.0);
     j->frac32.assign((size_t)g.B, 0.0);
-    std::vector<void *> bufs;   // everything this run allocates goes back on every exit path
-    struct Releaser {
-        ngp_ctx *c; std::vector<void *> &v;
-        ~Releaser() { for (void *q : v) c->release(q); }
-    } releaser{c, bufs};
-    auto dalloc = [&](void **q, size_t bytes) -> ngp_status {
-        ngp_status st = c->alloc(q, bytes);
-        if (!st) bufs.push_back(*q);
-        return st;
-    };
+    // the run's working storage comes from the context's workspace (ngp_ctx::ws_reserve): nothing
+    // to give back on the exit paths, the next call overwrites it
     void *Lbuf = nullptr, *dinv = nullptr, *tab = nullptr, *sig = nullptr;
     void *L32 = nullptr, *tmx = nullptr, *cnt = nullptr, *order_buf = nullptr, *order_prev = nullptr;
     RefineBufs rb;
@@ -1120,11 +1175,8 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
         ngp_status st = NGP_OK;
         // the estimate above leaves the allocator's rounding and other live handles out: when an
         // allocation fails the job is cut into more chunks instead of being refused
-        for (;; nchunks *= 2) {
-            Bc = (int)(((size_t)g.B + nchunks - 1) / nchunks);
-            // refinement sweeps need every block inverse M_j, not only the current one
-            mstep = refine ? (size_t)Bc * NB * NB : 0;
-            st = dalloc(&Lbuf, l_bytes * (size_t)Bc);
+        auto take_all = [&](WsPlan &dalloc) -> ngp_status {
+            ngp_status st = dalloc(&Lbuf, l_bytes * (size_t)Bc);
             if (!st) st = dalloc(&dinv, sizeof(double) * (size_t)Bc * NB * NB * (refine ? g.nb0 : 1));
             if (!st && g.lattice) st = dalloc(&tab, tab_bytes * (size_t)Bc);
             if (!st && g.lattice) st = dalloc(&sig, sig_bytes * (size_t)Bc);
@@ -1145,9 +1197,17 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
                 if (!st) st = dalloc((void **)&rb.delta, 16 * (size_t)Bc);
                 if (!st) st = dalloc((void **)&rb.items, 4 * (size_t)Bc);
             }
+            return st;
+        };
+        for (;; nchunks *= 2) {
+            Bc = (int)(((size_t)g.B + nchunks - 1) / nchunks);
+            // refinement sweeps need every block inverse M_j, not only the current one
+            mstep = refine ? (size_t)Bc * NB * NB : 0;
+            WsPlan measure{c, true}, take{c, false};
+            (void)take_all(measure);
+            st = c->ws_reserve(measure.total);
+            if (!st) st = take_all(take);
             if (st != NGP_ERR_TOO_LARGE || Bc <= 1) break;
-            for (void *q : bufs) c->release(q);
-            bufs.clear();
         }
         single_chunk = Bc >= g.B;
         if (st) return st;
@@ -1824,13 +1884,7 @@ extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *g
     hipStream_t s = c->stream;
     const DevSpec sp = dev_spec(j->spec);
     const int ntri = g.nb0 * (g.nb0 + 1) / 2;
-    std::vector<void *> owned;
-    auto freeall = [&] { for (void *q : owned) c->release(q); };
-    auto dalloc = [&](void **q, size_t bytes) -> ngp_status {
-        ngp_status st = c->alloc(q, bytes);
-        if (!st) owned.push_back(*q);
-        return st;
-    };
+    auto freeall = [] {};   // the working storage is the context's workspace: nothing to give back
     const size_t l_bytes = (size_t)g.item_stride * 8;
     const size_t tab_bytes = g.lattice ? 8 * (size_t)g.maxstat * g.R : 0;
     const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
@@ -1844,23 +1898,29 @@ extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *g
     std::vector<int32_t> h_items((size_t)B);   // alive until the stream is synchronised below
     ngp_status st;
     // the chunk is halved when the device cannot hold it after all (other handles, rounding)
-    for (;; Bc = (Bc + 1) / 2) {
-        if (!((st = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
-              (st = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
-              (g.lattice && ((st = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
-                             (st = dalloc(&d_sig, sig_bytes * (size_t)Bc)) ||
-                             (st = dalloc(&d_dtab, 3 * tab_bytes * (size_t)Bc)))) ||
-              (st = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||
-              (st = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) ||
-              (st = dalloc(&d_quad, 8 * (size_t)Bc)) ||
-              // a chunk that is cut finer (split 2 or 4) writes at most 4096 partial rows; a coarse one Bc ntri
-              (st = dalloc(&d_part,
+    auto take_all = [&](WsPlan &dalloc) -> ngp_status {
+        ngp_status r;
+        (void)((r = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
+               (r = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
+               (g.lattice && ((r = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
+                              (r = dalloc(&d_sig, sig_bytes * (size_t)Bc)) ||
+                              (r = dalloc(&d_dtab, 3 * tab_bytes * (size_t)Bc)))) ||
+               (r = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||
+               (r = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) ||
+               (r = dalloc(&d_quad, 8 * (size_t)Bc)) ||
+               // a chunk that is cut finer (split 2 or 4) writes at most 4096 partial rows; a coarse one Bc ntri
+               (r = dalloc(&d_part,
                            8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc), 4096) *
                                GP)) ||
-              (st = dalloc(&d_items, 4 * (size_t)B))))
-            break;
-        freeall();
-        owned.clear();
+               (r = dalloc(&d_items, 4 * (size_t)B)));
+        return r;
+    };
+    for (;; Bc = (Bc + 1) / 2) {
+        WsPlan measure{c, true}, take{c, false};
+        (void)take_all(measure);
+        st = c->ws_reserve(measure.total);
+        if (!st) st = take_all(take);
+        if (!st) break;
         if (st != NGP_ERR_TOO_LARGE || Bc <= 1) return st;
     }
     unsigned char *const io = j->io;

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Clock the chip holds under the fat kernel: GRBM_GUI_ACTIVE / 8 / dispatch duration (guide: DVFS give-back),
 # MFMA-busy share of those cycles.  Usage: gpurun -- bash scripts/gpu_clock.sh C3 16
-CFG=${1:-C3}; PART=${2:-16}
+CFG=${1:-C3}; PART=${2:-16}; SCEN=${3:--}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/clock_${CFG} -- python3 $R/scripts/pmc_workload.py $CFG $PART > $R/gpurun_out/clock_${CFG}.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/clock_${CFG} -- python3 $R/scripts/pmc_workload.py $CFG $PART predict $SCEN > $R/gpurun_out/clock_${CFG}.log 2>&1
 cd $R
 python3 - <<PY | tee gpurun_out/clock_${CFG}.txt
 import csv, glob, collections
