@@ -105,6 +105,11 @@ function logml_batch(c::Context, progs::Vector{Program}, t::Vector{Float64}, y::
     return out, info
 end
 
+"storage option of staged value jobs (include/ngp.h): results are bit-identical either way"
+set_structured_storage(c::Context, on::Bool) =
+    check(ccall((:ngp_set_structured_storage, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on),
+          "ngp_set_structured_storage")
+
 function logml_grad_batch(c::Context, progs::Vector{Program}, t::Vector{Float64},
                           y::VecOrMat{Float64})
     B, n = length(progs), length(t)

@@ -712,6 +712,7 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
             pi.logdet += h0;
             pi.info += h0;
             if (pi.tab) pi.tab += (size_t)h0 * g.maxstat * g.R;   // read by the column kernels (toep)
+            pi.n_fill_single = (int32_t)((long)p0.n_fill_single * (h1 - h0) / bc);   // byte accounting only
             if (pi.splitk_part) pi.splitk_part += (size_t)h0 * SPLITK_SLOTS * 4 * 64 * 64;
             if (i == 0) {
                 factor_chunk(ln, g, pi, h1 - h0, tm, dinv_step, sp, order_buf, order_prev, true);
@@ -1795,6 +1796,7 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
     g.maxstat = std::max(maxstat, 1);
     g.maxcp = std::max(maxcp, 1);
     std::vector<int32_t> h_q;
+    int32_t toep_stride = 0;
     {
         std::vector<double> real(t, t + n);
         double hh = 0.0;
@@ -1803,6 +1805,14 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
             g.lattice = 1;
             g.h = hh;
             g.R = R;
+            // a regular series: the tiles of one-leaf stationary trees are never stored (§4.11)
+            if (n >= 2 * NB) {
+                const long st0 = (long)h_q[1] - (long)h_q[0];
+                bool reg = st0 != 0;
+                for (int i = 2; i < n && reg; ++i)
+                    reg = (long)h_q[(size_t)i] - (long)h_q[(size_t)i - 1] == st0;
+                if (reg) toep_stride = (int32_t)std::labs(st0);
+            }
             h_q.resize((size_t)g.n0, 0);
         }
     }
@@ -1830,6 +1840,7 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     j->spec = c->spec;
+    if (c->toeplitz) g.toep = toep_stride;
     void *q = nullptr;
     ngp_status st = c->alloc(&q, j->io_bytes);
     if (st) return st;

@@ -66,7 +66,11 @@ __host__ __device__ inline bool prog_single_table(const DevProgram *P) {
 __host__ __device__ inline int prog_structure(const DevProgram *P) {
     return (P->n_rops == 1 && P->rops[0] == OP_TABLE) ? 1 : 0;
 }
-
+// Gradient jobs keep one table per LEAF (the contraction needs them), so there the structured items
+// are the trees that are ONE stationary leaf (slot 0 is then the whole tree's table)
+__host__ __device__ inline int prog_structure_grad(const DevProgram *P) {
+    return (P->n_ops == 1 && P->ops[0] >= NGP_OP_SQEXP && P->ops[0] <= NGP_OP_PERIODIC) ? 1 : 0;
+}
 struct DevSpec {
     int32_t se_form, periodic_form, cp_form, precision;
     double  jitter;
@@ -104,6 +108,14 @@ struct JobGeom {
     int64_t ld;        // row stride of the factor storage (= n0)
     int64_t item_stride;  // elements per item in the factor storage
 };
+
+// ... and a tile (rows 64 r .., columns 64 c .., r > c) is never stored iff it lies inside the real
+// points (the padding of a gradient job's last block is identity, not Toeplitz) and a fat step is
+// the first to touch it (an odd block-column count starts with a FULL step on column 0)
+__host__ __device__ inline bool grad_tile_unstored(const JobGeom &g, int r, int c) {
+    const int o = (g.nb0 >= 3 && (g.nb0 & 1)) ? 1 : 0;
+    return g.toep > 0 && r > c && c >= o && (r + 1) * NB <= g.n_real;
+}
 
 struct ChunkPtrs {
     double       *L;      // [Bc][(n0 + naux_pad) x n0] factor + aux rows, row-major

@@ -449,6 +449,11 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
         }
         aux = true;
     }
+    if constexpr (GRADJOB) {
+        // Toeplitz gradient jobs: the tiles of one-leaf stationary trees that a fat step touches
+        // first are never stored (the column kernels take them from the leaf's table)
+        if (!aux && grad_tile_unstored(g, r, c) && prog_structure_grad(&P)) return;
+    }
     // thread = (column pair tx, 8-row group ty): two adjacent columns per thread -> 16-byte stores
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int col = c * NB + 2 * tx;

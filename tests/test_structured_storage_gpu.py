@@ -107,3 +107,23 @@ def test_lattice_stride_two_and_a_gap(ctx):
     cond = np.linalg.cond(oracle_np.cov(progs[-2], tt, tt, True))
     ref = oracle_np.nowcast(progs[-2], tg, w.y, t_add + 2 * h, w.y_add, t_new + 2 * h)
     check("toeplitz storage: logml vs oracle", on["logml_full"][-2], ref[1], TOL_LOGML, cond)
+
+
+@pytest.mark.parametrize("n,P", [(256 + 5, 6), (192 + 17, 5), (1024 + 1, 9), (1600 + 3, 64)])
+def test_gradient_outputs_are_bit_identical_with_the_option_off(ctx, n, P):
+    """gradient jobs keep one table per leaf: there the trees that are ONE stationary leaf are the
+    structured items, and only the tiles inside the real points (the padding of the last block is
+    identity).  logml and gradient must not change by a bit; one item against the oracle."""
+    from oracle import oracle_c
+    w = make_workload("C2", n=n, P=P, D=1)
+    progs = _mixed_ensemble(w)
+    on, off = _both(ctx, lambda: ctx.logml_grad_batch(progs, w.t, w.y))
+    assert np.array_equal(on[0], off[0]) and np.array_equal(on[2], off[2]) and not on[2].any()
+    for a, b in zip(on[1], off[1]):
+        assert np.array_equal(a, b)
+    if n <= 300:
+        p = len(progs) - 4          # the squared-exponential leaf
+        lm, g, info = oracle_c.logml_grad(progs[p], w.t, w.y)
+        cond = np.linalg.cond(oracle_np.cov(progs[p], w.t, w.t, True))
+        check("structured gradient job: logml vs oracle", on[0][p], lm, TOL_LOGML, cond)
+        check("structured gradient job: gradient vs oracle", on[1][p], g, 1e-7, cond)
