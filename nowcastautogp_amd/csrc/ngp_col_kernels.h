@@ -429,7 +429,7 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
                                                     int lane, double *buf, Probe &probe,
                                                     float *Lr32 = nullptr,
                                                     float *tmax_out = nullptr, int synth = 0,
-                                                    const double *ksl = nullptr) {
+                                                    const double *ksl = nullptr, int nit = 4) {
     double amax = 0.0;
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;          // row of S' inside a 16-tile
@@ -472,13 +472,14 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
     load_k(0);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {                // 16 tile rows per pass
+        if (it >= nit) break;                       // an aux tile's zero rows: nothing to solve or store
         double c4[4][4];   // C' = K' - S' for this 16-row group of the tile
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) c4[jt][r] = kv[jt][r] - acc4[jt][it][r];
         probe.mark_after(12 + 3 * it, c4[3][3] + c4[0][0] + c4[1][2] + c4[2][1]);
-        if (it + 1 < 4) load_k(it + 1);
+        if (it + 1 < nit) load_k(it + 1);
         // 16 strip groups cb4 = 4 ct + cq (output rows 4 cb4 ..: C' tiles jt <= ct).  The M strips of
         // group cb4 + 1 are requested before the result of group cb4 is written to the LDS tile:
         // behind that write hipcc would not move them (same LDS array), and every group would
@@ -544,7 +545,7 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
 __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, int c0,
                                                        const double (*acc4)[4][4], int lane,
                                                        bool fresh = false,
-                                                       const double *ksl = nullptr) {
+                                                       const double *ksl = nullptr, int nit = 4) {
     const int n16 = lane & 15, isub = lane >> 4;
     const int jj0 = 4 * (n16 >> 2) + isub;
     double *base = rows + c0 + jj0;
@@ -580,7 +581,8 @@ __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, in
         for (int r = 0; r < 4; ++r) v[0][jt][r] = base[roff[r] + 16 * jt];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        if (it + 1 < 4) {
+        if (it >= nit) break;       // an aux tile's zero rows stay as they are
+        if (it + 1 < nit) {
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
@@ -836,8 +838,11 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
             p.L32 + (long)item * g.item_stride + rowbase * ld,
             p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
     } else {
+        // an aux tile with at most 16 real rows: its other rows are zero and stay zero (fat kernel)
+        const int nit = (tile >= st.nmain && g.naux - NB * (tile - st.nmain) <= 16) ? 1 : 4;
         solve_and_store_lds<false, IDENT>(acc4, Lr, reinterpret_cast<const double *>(smem), ld,
-                                          kmax, lane, buf, probe, nullptr, nullptr, synth);
+                                          kmax, lane, buf, probe, nullptr, nullptr, synth, nullptr,
+                                          nit);
     }
     probe.mark_after(5, lane);
     probe.drain();
@@ -941,6 +946,15 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
             grad_tile_unstored(g, j + 1 + tile, col ? j + 1 : j))
             structured = prog_structure_grad(p.progs + item) != 0;
     }
+    // 16-row groups of the wave's tile that hold real rows: 4 for main tiles and full aux tiles; an
+    // aux tile with at most 16 real rows (see the k-loop) works on its first group only
+    int nit = 4;
+    if constexpr (!MIXED && SPLITK == 0) {
+        if (valid && tile >= st.nmain) {
+            const int real = g.naux - NB * (tile - st.nmain);
+            if (real <= 16) nit = 1;
+        }
+    }
     // gradient jobs (aux rows [I ; y']): identity tile a is zero left of block column a.  The two
     // tiles of a workgroup share the staged k-range, so it starts at the smaller of their starts;
     // a workgroup whose tiles are all still zero leaves before the first barrier.
@@ -1021,7 +1035,8 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 
     // one 16-deep fp64 chunk in buffer `buf`: 256 mfma4 per wave.  (Requesting the operands of
     // k-step s+1 before the MFMAs of k-step s — two register sets — measured 1 % slower.)
-    auto mult64 = [&](const char *buf) {
+    auto mult64 = [&](const char *buf, auto nit_c) {
+        constexpr int NIT = decltype(nit_c)::value;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             double a[4];
@@ -1029,7 +1044,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
             for (int u = 0; u < 4; ++u)
                 a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 2 * BLKB);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
+            for (int it = 0; it < NIT; ++it) {
                 Rot4 br;
                 br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 2 * BLKB);
                 br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 2 * BLKB);
@@ -1054,13 +1069,26 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
         if (nchunks > 0) {
             stage(0, kbeg);
             __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) ahead of the barrier
-            for (int c = 0; c < nchunks; ++c) {
-                const int cur = c & 1;
-                if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
-                mult64(smem + cur * STAGE);
-                __syncthreads();
-                if (c == 0) probe.mark(1);
-                if (c == nchunks / 2) probe.mark(2);
+            // an aux tile whose real rows fit its first 16-row group (the 11 rows of a predictive
+            // job: appended points, forecast dates, y'; the single y' row of a gradient job)
+            // multiplies that group only — the other 48 rows are zero and stay zero.  Two loops,
+            // not one loop with two bodies: that form spilled 400 B per lane.
+            if (nit == 1) {
+                for (int c = 0; c < nchunks; ++c) {
+                    const int cur = c & 1;
+                    if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
+                    mult64(smem + cur * STAGE, std::integral_constant<int, 1>{});
+                    __syncthreads();
+                }
+            } else {
+                for (int c = 0; c < nchunks; ++c) {
+                    const int cur = c & 1;
+                    if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
+                    mult64(smem + cur * STAGE, std::integral_constant<int, 4>{});
+                    __syncthreads();
+                    if (c == 0) probe.mark(1);
+                    if (c == nchunks / 2) probe.mark(2);
+                }
             }
         }
     } else {
@@ -1246,7 +1274,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
                     stage(cur ^ 1, kt_cur * NB + LDS_KC * sub);
                     ++sub;
                 }
-                mult64(smem + cur * STAGE);
+                mult64(smem + cur * STAGE, std::integral_constant<int, 4>{});
                 __syncthreads();
             }
         }
@@ -1311,7 +1339,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 
     double *Lr = Lit + tile_row0(tile) * ld;
     if (col) {
-        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane, IDENT && synth != 0, ksl);
+        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane, IDENT && synth != 0, ksl, nit);
     } else if constexpr (MIXED) {
         const int rt = (tile < st.nmain) ? j + 1 + tile : g.nb0 + (tile - st.nmain);
         solve_and_store_lds<true>(
@@ -1323,7 +1351,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
         solve_and_store_lds<false, IDENT>(
             acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane,
             reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES), probe, nullptr,
-            nullptr, synth, ksl);
+            nullptr, synth, ksl, nit);
     }
     probe.mark(5);
     probe.drain();       // stores retired (vmcnt(0))
