@@ -946,15 +946,6 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
             grad_tile_unstored(g, j + 1 + tile, col ? j + 1 : j))
             structured = prog_structure_grad(p.progs + item) != 0;
     }
-    // 16-row groups of the wave's tile that hold real rows: 4 for main tiles and full aux tiles; an
-    // aux tile with at most 16 real rows (see the k-loop) works on its first group only
-    int nit = 4;
-    if constexpr (!MIXED && SPLITK == 0) {
-        if (valid && tile >= st.nmain) {
-            const int real = g.naux - NB * (tile - st.nmain);
-            if (real <= 16) nit = 1;
-        }
-    }
     // gradient jobs (aux rows [I ; y']): identity tile a is zero left of block column a.  The two
     // tiles of a workgroup share the staged k-range, so it starts at the smaller of their starts;
     // a workgroup whose tiles are all still zero leaves before the first barrier.
@@ -978,6 +969,17 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
         kbeg = kfirst;
         const int a = tile - st.nmain;
         if (valid && a < g.nb0 && a > j) valid = false;
+    }
+    // 16-row groups of the wave's tile that hold real rows: 4 for main tiles and full aux tiles; an
+    // aux tile with at most 16 real rows (see the k-loop) works on its first group only; a wave
+    // without a tile (an odd tile count, an identity tile of a gradient job that is still zero)
+    // stages its rows and keeps the barriers but multiplies nothing
+    // (only gradient jobs have such waves in numbers — the identity tiles that are still zero; in
+    // the value kernel the third loop cost 0.5 % and saved nothing)
+    int nit = 4;
+    if constexpr (!MIXED && SPLITK == 0) {
+        if (IDENT && !valid) nit = 0;
+        else if (valid && tile >= st.nmain && g.naux - NB * (tile - st.nmain) <= 16) nit = 1;
     }
     const int r16 = lane & 15, q = lane >> 4;
     auto tile_row0 = [&](int t) -> long {
@@ -1073,7 +1075,12 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
             // job: appended points, forecast dates, y'; the single y' row of a gradient job)
             // multiplies that group only — the other 48 rows are zero and stay zero.  Two loops,
             // not one loop with two bodies: that form spilled 400 B per lane.
-            if (nit == 1) {
+            if (IDENT && nit == 0) {
+                for (int c = 0; c < nchunks; ++c) {
+                    if (c + 1 < nchunks) stage((c & 1) ^ 1, kbeg + (c + 1) * LDS_KC);
+                    __syncthreads();
+                }
+            } else if (nit == 1) {
                 for (int c = 0; c < nchunks; ++c) {
                     const int cur = c & 1;
                     if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
