@@ -839,7 +839,8 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
             p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
     } else {
         // an aux tile with at most 16 real rows: its other rows are zero and stay zero (fat kernel)
-        const int nit = (tile >= st.nmain && g.naux - NB * (tile - st.nmain) <= 16) ? 1 : 4;
+        int nit = (tile >= st.nmain && g.naux - NB * (tile - st.nmain) <= 16) ? 1 : 4;
+        if (IDENT && tile < st.nmain && g.n_real - NB * (j + 1 + tile) <= 16) nit = 1;   // padded last row tile
         solve_and_store_lds<false, IDENT>(acc4, Lr, reinterpret_cast<const double *>(smem), ld,
                                           kmax, lane, buf, probe, nullptr, nullptr, synth, nullptr,
                                           nit);
@@ -980,6 +981,9 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
     if constexpr (!MIXED && SPLITK == 0) {
         if (IDENT && !valid) nit = 0;
         else if (valid && tile >= st.nmain && g.naux - NB * (tile - st.nmain) <= 16) nit = 1;
+        // gradient jobs pad the main block to a multiple of 64 with identity rows: the last row tile
+        // of a series of 2048 + 1 points has one real row, the other 63 are zero left of the diagonal
+        else if (IDENT && valid && tile < st.nmain && g.n_real - NB * (j + 1 + tile) <= 16) nit = 1;
     }
     const int r16 = lane & 15, q = lane >> 4;
     auto tile_row0 = [&](int t) -> long {

@@ -1572,7 +1572,10 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
     const int kbeg = I0 * NB;
-    const int nchunks = (g.n0 - kbeg) / LDS_KC;
+    // columns beyond the real points are the identity padding of the last block: the rows of W that
+    // matter are zero there, so the sum stops at the chunk that holds the last real column
+    const int kend = min(g.n0, (g.n_real + LDS_KC - 1) / LDS_KC * LDS_KC);
+    const int nchunks = max(kend - kbeg, LDS_KC) / LDS_KC;
     stage(0, kbeg);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
