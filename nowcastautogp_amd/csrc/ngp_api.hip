@@ -1733,7 +1733,8 @@ extern "C" ngp_status ngp_cov_batch(ngp_ctx *c, int32_t B, const ngp_kernel *ker
 // ---------------------------------------------------------------------------------------
 // gradient jobs: the inputs of ngp_logml_grad_batch kept on the device across calls
 // ---------------------------------------------------------------------------------------
-struct ngp_grad_job {
+struct GradLeaf {
+    bool toep_path = false;                // the Toeplitz gradient path
     ngp_ctx *ctx = nullptr;
     JobGeom g{};
     int B = 0, n = 0;
@@ -1750,14 +1751,19 @@ struct ngp_grad_job {
     ngp_spec spec{};
 };
 
-extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
-                                     const double *t, const double *y, int64_t ldy,
-                                     ngp_grad_job **out) {
+namespace {
+
+// toep_path: the items are stationary trees on a regular series — aux rows [y' ; e_1'] instead of
+// [I ; y'] (the caller, ngp_grad_stage, has checked both)
+ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
+                           const double *t, const double *y, int64_t ldy, bool toep_path,
+                           GradLeaf **out) {
     if (!c || !out || !kernels || !t || !y || B <= 0 || n <= 0) return NGP_ERR_ARG;
     *out = nullptr;
-    ngp_grad_job *j = new (std::nothrow) ngp_grad_job();
+    GradLeaf *j = new (std::nothrow) GradLeaf();
     if (!j) return NGP_ERR_TOO_LARGE;
-    std::unique_ptr<ngp_grad_job> guard(j);
+    std::unique_ptr<GradLeaf> guard(j);
+    j->toep_path = toep_path;
     j->ctx = c;
     j->B = B;
     j->n = n;
@@ -1783,10 +1789,11 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
     g.n0 = (n + NB - 1) / NB * NB;
     g.nb0 = g.n0 / NB;
     g.n_real = n;
-    g.aux_identity = 1;
+    g.aux_identity = toep_path ? 0 : 1;
+    g.aux_e1 = toep_path ? 1 : 0;
     g.maxops = maxops;
-    g.naux = g.n0 + 1;
-    g.naux_pad = g.n0 + NB;
+    g.naux = toep_path ? 2 : g.n0 + 1;
+    g.naux_pad = toep_path ? NB : g.n0 + NB;
     g.D = 1;
     g.y_shared = (ldy == 0) ? 1 : 0;
     g.ld = g.n0;
@@ -1796,7 +1803,6 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
     g.maxstat = std::max(maxstat, 1);
     g.maxcp = std::max(maxcp, 1);
     std::vector<int32_t> h_q;
-    int32_t toep_stride = 0;
     {
         std::vector<double> real(t, t + n);
         double hh = 0.0;
@@ -1805,14 +1811,6 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
             g.lattice = 1;
             g.h = hh;
             g.R = R;
-            // a regular series: the tiles of one-leaf stationary trees are never stored (§4.11)
-            if (n >= 2 * NB) {
-                const long st0 = (long)h_q[1] - (long)h_q[0];
-                bool reg = st0 != 0;
-                for (int i = 2; i < n && reg; ++i)
-                    reg = (long)h_q[(size_t)i] - (long)h_q[(size_t)i - 1] == st0;
-                if (reg) toep_stride = (int32_t)std::labs(st0);
-            }
             h_q.resize((size_t)g.n0, 0);
         }
     }
@@ -1840,7 +1838,8 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     j->spec = c->spec;
-    if (c->toeplitz) g.toep = toep_stride;
+    // (gradient jobs store every tile: their tables are per leaf, and on a regular series the
+    // stationary trees — the ones structured storage could serve — are on the Toeplitz path)
     void *q = nullptr;
     ngp_status st = c->alloc(&q, j->io_bytes);
     if (st) return st;
@@ -1867,8 +1866,7 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
     return NGP_OK;
 }
 
-extern "C" ngp_status ngp_grad_job_set_params(ngp_grad_job *j, const double *params,
-                                              const double *noise) {
+ngp_status grad_leaf_set_params(GradLeaf *j, const double *params, const double *noise) {
     if (!j || !params || !noise) return NGP_ERR_ARG;
     size_t off = 0;
     for (int i = 0; i < j->B; ++i) {
@@ -1884,7 +1882,7 @@ extern "C" ngp_status ngp_grad_job_set_params(ngp_grad_job *j, const double *par
     return NGP_OK;
 }
 
-extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *grad, int32_t *info) {
+ngp_status grad_leaf_run(GradLeaf *j, double *logml, double *grad, int32_t *info) {
     if (!j || !grad) return NGP_ERR_ARG;
     ngp_ctx *c = j->ctx;
     const JobGeom &g = j->g;
@@ -1899,8 +1897,14 @@ extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *g
     const size_t l_bytes = (size_t)g.item_stride * 8;
     const size_t tab_bytes = g.lattice ? 8 * (size_t)g.maxstat * g.R : 0;
     const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
-    const size_t item_bytes = l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 +
-                              8 * (size_t)g.n0 + 8 * (size_t)ntri * GP;
+    const bool tp = j->toep_path;
+    const int nd = (g.n_real + 255) / 256;          // Toeplitz path: blocks of 256 lattice distances
+    const size_t aux_bytes = 8 * (size_t)g.naux_pad * g.n0;
+    const size_t item_bytes =
+        tp ? l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)NB * NB * g.nb0 + aux_bytes +
+                 8 * (size_t)g.n0 + 8 * (size_t)nd * GP
+           : l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 + 8 * (size_t)g.n0 +
+                 8 * (size_t)ntri * GP;
     if ((size_t)B * item_bytes > c->mem_cap) c->refresh_mem_cap();   // large job: today's figure
     int Bc = (int)std::min<size_t>(std::min<size_t>((size_t)B, MAX_CHUNK_ITEMS),
                                    std::max<size_t>(1, c->mem_cap / item_bytes));
@@ -1912,17 +1916,20 @@ extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *g
     auto take_all = [&](WsPlan &dalloc) -> ngp_status {
         ngp_status r;
         (void)((r = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
-               (r = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB)) ||
+               // the Toeplitz path keeps every block inverse M_j for its backward sweep
+               (r = dalloc(&d_dinv, 8 * (size_t)Bc * NB * NB * (tp ? g.nb0 : 1))) ||
                (g.lattice && ((r = dalloc(&d_tab, tab_bytes * (size_t)Bc)) ||
                               (r = dalloc(&d_sig, sig_bytes * (size_t)Bc)) ||
                               (r = dalloc(&d_dtab, 3 * tab_bytes * (size_t)Bc)))) ||
-               (r = dalloc(&d_kinv, 8 * (size_t)Bc * g.n0 * g.n0)) ||
-               (r = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) ||
+               // general path: K^-1 [n0 x n0]; Toeplitz path: A = [a' ; x'] (one aux tile)
+               (r = dalloc(&d_kinv, tp ? aux_bytes * (size_t)Bc : 8 * (size_t)Bc * g.n0 * g.n0)) ||
+               (r = dalloc(&d_alpha, 8 * (size_t)Bc * g.n0)) ||      // Toeplitz path: w per distance
                (r = dalloc(&d_quad, 8 * (size_t)Bc)) ||
                // a chunk that is cut finer (split 2 or 4) writes at most 4096 partial rows; a coarse one Bc ntri
                (r = dalloc(&d_part,
-                           8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc), 4096) *
-                               GP)) ||
+                           tp ? 8 * (size_t)Bc * nd * GP
+                              : 8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc),
+                                                     4096) * GP)) ||
                (r = dalloc(&d_items, 4 * (size_t)B)));
         return r;
     };
@@ -1967,20 +1974,32 @@ extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *g
         if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
         // K's lower blocks, the y' tile row and the zero blocks (a, a-1): the identity block of
         // the aux rows is synthesised by the column kernels, not written
-        tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + 2.0 * NB * (double)g.n0),
+        tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + (tp ? 1.0 : 2.0) * NB * (double)g.n0),
                [&] { launch_fill(g, p, bc, sp, s); });
-        factor_chunk(lane_of(c), g, p, bc, tm);
+        const size_t mstep = tp ? (size_t)bc * NB * NB : 0;
+        factor_chunk(lane_of(c), g, p, bc, tm, mstep);
         const double n3 = (double)g.n0 * g.n0 * g.n0;
-        tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
-            launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
-                             (double *)d_quad, bc, s, c->side, c->ev_fork, c->ev_join);
-        });
+        if (tp) {
+            // z'z, then A = X K^-1 by one backward sweep of the two aux rows (class 10 with the
+            // other backward sweeps of the library)
+            tm.run(10, 0.0, bc * 8.0 * g.n0, [&] { launch_toep_quad(g, (const double *)d_L, (double *)d_quad, bc, s); });
+            for (int cc = g.nb0 - 1; cc >= 0; --cc)
+                tm.run(10, bc * 2.0 * 2.0 * NB * (double)(cc + 1) * NB,
+                       bc * 8.0 * ((double)NB * NB * (cc + 1) + 2.0 * 2.0 * NB * (cc + 1)), [&] {
+                           launch_aux_back(g, p, p.dinv, mstep, (double *)d_kinv, 0, bc, cc, s);
+                       });
+        } else {
+            tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
+                launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
+                                 (double *)d_quad, bc, s, c->side, c->ev_fork, c->ev_join);
+            });
+        }
         // the chunk's items sorted by tree size: every size class runs on the contraction kernel
         // sized for it
         // (small launches — the 24- or 64-particle calls of a fit on short series — stay ONE launch
         // sized by the largest tree: up to five dependent launches of a few microseconds each cost
         // more there than the occupancy of the smaller instantiations gains)
-        const bool by_size = g.lattice && (long)ntri * bc > 4096;
+        const bool by_size = g.lattice && (tp ? (long)nd * bc > 512 : (long)ntri * bc > 4096);
         int32_t counts[GRAD_BUCKETS] = {};
         if (by_size) {
             for (int i = 0; i < bc; ++i) ++counts[grad_bucket(j->n_ops[(size_t)(b0 + i)])];
@@ -1997,13 +2016,22 @@ extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *g
                 return (ngp_status)ce;
             }
         }
-        tm.run(11, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
-            launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
-                                 (const double *)d_quad, (double *)d_part,
-                                 (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc,
-                                 sp, s, by_size ? (const int32_t *)d_items + b0 : nullptr, counts,
-                                 c->side, c->ev_fork, c->ev_join);
-        });
+        if (tp) {
+            tm.run(11, 0.0, bc * 8.0 * 3.0 * (double)g.n0, [&] {
+                launch_toep_grad(g, p, (const double *)d_kinv, (double *)d_alpha, (const double *)d_quad,
+                                 (double *)d_part, (double *)d_grad + (int64_t)b0 * GP,
+                                 (double *)d_logml + b0, bc, sp, s,
+                                 by_size ? (const int32_t *)d_items + b0 : nullptr, counts);
+            });
+        } else {
+            tm.run(11, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
+                launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
+                                     (const double *)d_quad, (double *)d_part,
+                                     (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc,
+                                     sp, s, by_size ? (const int32_t *)d_items + b0 : nullptr, counts,
+                                     c->side, c->ev_fork, c->ev_join);
+            });
+        }
     }
     e = hipMemcpyAsync(j->h_out.data(), d_info, j->h_out.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -2029,7 +2057,7 @@ extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *g
     return NGP_OK;
 }
 
-extern "C" void ngp_grad_job_destroy(ngp_grad_job *j) {
+void grad_leaf_destroy(GradLeaf *j) {
     if (!j) return;
     {
         std::lock_guard<std::mutex> lk(j->ctx->mu);
@@ -2038,6 +2066,156 @@ extern "C" void ngp_grad_job_destroy(ngp_grad_job *j) {
         if (!j->h_in.empty()) (void)hipStreamSynchronize(j->ctx->stream);
         j->ctx->release(j->io);
     }
+    delete j;
+}
+
+}  // namespace
+
+// The public handle: the batch as the caller sees it, carried by up to two leaves — the items that
+// are stationary trees, when the series is regular, on the Toeplitz path, the others on the general
+// one — with the index maps that scatter results and parameters.
+struct ngp_grad_job {
+    ngp_ctx *ctx = nullptr;
+    int B = 0;
+    GradLeaf *gen = nullptr, *toep = nullptr;
+    std::vector<int32_t> idx_gen, idx_toep;     // leaf item -> caller's item
+    std::vector<size_t> poff, goff;             // [B + 1] offsets of an item's parameters / gradient
+    std::vector<double> buf_p, buf_n, buf_lm, buf_g;
+    std::vector<int32_t> buf_info;
+};
+
+extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
+                                     const double *t, const double *y, int64_t ldy,
+                                     ngp_grad_job **out) {
+    if (!c || !out || !kernels || !t || !y || B <= 0 || n <= 0) return NGP_ERR_ARG;
+    *out = nullptr;
+    for (int i = 0; i < B; ++i) {
+        ngp_status st = check_program(&kernels[i]);
+        if (st) return st;
+    }
+    std::unique_ptr<ngp_grad_job> j(new (std::nothrow) ngp_grad_job());
+    if (!j) return NGP_ERR_TOO_LARGE;
+    j->ctx = c;
+    j->B = B;
+    j->poff.assign((size_t)B + 1, 0);
+    j->goff.assign((size_t)B + 1, 0);
+    for (int i = 0; i < B; ++i) {
+        j->poff[(size_t)i + 1] = j->poff[(size_t)i] + (size_t)kernels[i].n_params;
+        j->goff[(size_t)i + 1] = j->goff[(size_t)i] + (size_t)kernels[i].n_params + 1;
+    }
+    // the Toeplitz path: a regular series (constant lattice stride over all n points), at least two
+    // blocks, short enough for the weights kernel's LDS image, and a tree without Linear or
+    // ChangePoint nodes
+    bool regular = false;
+    bool on;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        on = c->toeplitz;
+    }
+    if (on && n >= 2 * NB && n <= 8192) {
+        std::vector<double> real(t, t + n);
+        std::vector<int32_t> q;
+        double hh = 0.0;
+        int R = 0;
+        if (detect_lattice(real, &hh, &q, &R)) {
+            const long st0 = (long)q[1] - (long)q[0];
+            regular = st0 != 0;
+            for (int i = 2; i < n && regular; ++i) regular = (long)q[(size_t)i] - (long)q[(size_t)i - 1] == st0;
+        }
+    }
+    for (int i = 0; i < B; ++i) {
+        // (trees of more than 16 leaves stay on the general path: the 1-D contraction runs on the
+        // register-accumulator kernels, which end there)
+        bool stationary = regular && kernels[i].n_ops <= 31;
+        for (int k = 0; stationary && k < kernels[i].n_ops; ++k)
+            stationary = kernels[i].ops[k] != NGP_OP_LINEAR && kernels[i].ops[k] != NGP_OP_CHANGEPOINT;
+        (stationary ? j->idx_toep : j->idx_gen).push_back(i);
+    }
+    // A batch that is split runs its two leaves one after the other: two chains of dependent launches
+    // instead of one.  That pays when the leaves are throughput-bound (12,800 items at n = 2049:
+    // 2,615 -> 1,794 ms) and costs when they are latency-bound (24 items at n = 208: 615 -> 790 us; 64 at
+    // n = 2048: 15.9 -> 16.3 ms), so a mixed batch is split only from SPLIT_MIN_ITEMS on; a batch
+    // of stationary trees only is never split and always takes the Toeplitz path.
+    constexpr int SPLIT_MIN_ITEMS = 256;
+    if (!j->idx_gen.empty() && !j->idx_toep.empty() && B < SPLIT_MIN_ITEMS) {
+        j->idx_toep.clear();
+        j->idx_gen.resize((size_t)B);
+        for (int i = 0; i < B; ++i) j->idx_gen[(size_t)i] = i;
+    }
+    auto stage_leaf = [&](const std::vector<int32_t> &idx, bool toep_path, GradLeaf **leaf) -> ngp_status {
+        if (idx.empty()) return NGP_OK;
+        if ((int)idx.size() == B)   // the whole batch: the caller's arrays as they are
+            return grad_leaf_stage(c, B, kernels, n, t, y, ldy, toep_path, leaf);
+        std::vector<ngp_kernel> ks(idx.size());
+        for (size_t a = 0; a < idx.size(); ++a) ks[a] = kernels[idx[a]];
+        if (ldy == 0) return grad_leaf_stage(c, (int32_t)idx.size(), ks.data(), n, t, y, 0, toep_path, leaf);
+        std::vector<double> ys(idx.size() * (size_t)n);
+        for (size_t a = 0; a < idx.size(); ++a)
+            std::memcpy(ys.data() + a * (size_t)n, y + (int64_t)idx[a] * ldy, 8 * (size_t)n);
+        return grad_leaf_stage(c, (int32_t)idx.size(), ks.data(), n, t, ys.data(), n, toep_path, leaf);
+    };
+    ngp_status st = stage_leaf(j->idx_gen, false, &j->gen);
+    if (!st) st = stage_leaf(j->idx_toep, true, &j->toep);
+    if (st) {
+        grad_leaf_destroy(j->gen);
+        grad_leaf_destroy(j->toep);
+        return st;
+    }
+    *out = j.release();
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_grad_job_set_params(ngp_grad_job *j, const double *params,
+                                              const double *noise) {
+    if (!j || !params || !noise) return NGP_ERR_ARG;
+    auto set_leaf = [&](GradLeaf *leaf, const std::vector<int32_t> &idx) -> ngp_status {
+        if (!leaf) return NGP_OK;
+        if ((int)idx.size() == j->B) return grad_leaf_set_params(leaf, params, noise);
+        j->buf_p.clear();
+        j->buf_n.clear();
+        for (int32_t i : idx) {
+            j->buf_p.insert(j->buf_p.end(), params + j->poff[(size_t)i], params + j->poff[(size_t)i + 1]);
+            j->buf_n.push_back(noise[i]);
+        }
+        if (j->buf_p.empty()) j->buf_p.push_back(0.0);
+        return grad_leaf_set_params(leaf, j->buf_p.data(), j->buf_n.data());
+    };
+    ngp_status st = set_leaf(j->gen, j->idx_gen);
+    if (!st) st = set_leaf(j->toep, j->idx_toep);
+    return st;
+}
+
+extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *grad, int32_t *info) {
+    if (!j || !grad) return NGP_ERR_ARG;
+    auto run_leaf = [&](GradLeaf *leaf, const std::vector<int32_t> &idx) -> ngp_status {
+        if (!leaf) return NGP_OK;
+        if ((int)idx.size() == j->B) return grad_leaf_run(leaf, logml, grad, info);
+        size_t ng = 0;
+        for (int32_t i : idx) ng += j->goff[(size_t)i + 1] - j->goff[(size_t)i];
+        j->buf_lm.resize(idx.size());
+        j->buf_info.resize(idx.size());
+        j->buf_g.resize(ng);
+        ngp_status st = grad_leaf_run(leaf, j->buf_lm.data(), j->buf_g.data(), j->buf_info.data());
+        if (st) return st;
+        size_t off = 0;
+        for (size_t a = 0; a < idx.size(); ++a) {
+            const size_t i = (size_t)idx[a], len = j->goff[i + 1] - j->goff[i];
+            std::memcpy(grad + j->goff[i], j->buf_g.data() + off, 8 * len);
+            off += len;
+            if (logml) logml[i] = j->buf_lm[a];
+            if (info) info[i] = j->buf_info[a];
+        }
+        return NGP_OK;
+    };
+    ngp_status st = run_leaf(j->gen, j->idx_gen);
+    if (!st) st = run_leaf(j->toep, j->idx_toep);
+    return st;
+}
+
+extern "C" void ngp_grad_job_destroy(ngp_grad_job *j) {
+    if (!j) return;
+    grad_leaf_destroy(j->gen);
+    grad_leaf_destroy(j->toep);
     delete j;
 }
 

@@ -942,11 +942,6 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
         if (g.toep && st.first_touch && valid && tile < st.nmain && !(col && tile == 0))
             structured = prog_structure(p.progs + item) != 0;
     }
-    if constexpr (!MIXED && IDENT) {   // gradient jobs: one-leaf stationary trees, real tiles only
-        if (g.toep && valid && tile < st.nmain && !(col && tile == 0) &&
-            grad_tile_unstored(g, j + 1 + tile, col ? j + 1 : j))
-            structured = prog_structure_grad(p.progs + item) != 0;
-    }
     // gradient jobs (aux rows [I ; y']): identity tile a is zero left of block column a.  The two
     // tiles of a workgroup share the staged k-range, so it starts at the smaller of their starts;
     // a workgroup whose tiles are all still zero leaves before the first barrier.

@@ -66,11 +66,6 @@ __host__ __device__ inline bool prog_single_table(const DevProgram *P) {
 __host__ __device__ inline int prog_structure(const DevProgram *P) {
     return (P->n_rops == 1 && P->rops[0] == OP_TABLE) ? 1 : 0;
 }
-// Gradient jobs keep one table per LEAF (the contraction needs them), so there the structured items
-// are the trees that are ONE stationary leaf (slot 0 is then the whole tree's table)
-__host__ __device__ inline int prog_structure_grad(const DevProgram *P) {
-    return (P->n_ops == 1 && P->ops[0] >= NGP_OP_SQEXP && P->ops[0] <= NGP_OP_PERIODIC) ? 1 : 0;
-}
 struct DevSpec {
     int32_t se_form, periodic_form, cp_form, precision;
     double  jitter;
@@ -99,6 +94,7 @@ struct JobGeom {
     int32_t n_real;    // main-block points that are data; rows/cols beyond are identity padding
     int32_t aux_identity;  // 1: aux rows are [I_n0 ; y'] (gradient path: W = L^-T)
     int32_t maxops;    // longest program of the batch (gradient jobs: picks the contraction kernel)
+    int32_t aux_e1;    // 1: the Toeplitz gradient path — aux rows [y' ; e_1'] (the row after y' is e_1')
     int32_t toep;      // > 0: the main-block points sit on the lattice at a constant stride (q_i = q_0
                        // +- toep i), so K of a stationary tree is Toeplitz: K_ik = tab[toep |i - k|].  The
                        // fill then writes only the diagonal tiles and the aux rows of structured items
@@ -108,14 +104,6 @@ struct JobGeom {
     int64_t ld;        // row stride of the factor storage (= n0)
     int64_t item_stride;  // elements per item in the factor storage
 };
-
-// ... and a tile (rows 64 r .., columns 64 c .., r > c) is never stored iff it lies inside the real
-// points (the padding of a gradient job's last block is identity, not Toeplitz) and a fat step is
-// the first to touch it (an odd block-column count starts with a FULL step on column 0)
-__host__ __device__ inline bool grad_tile_unstored(const JobGeom &g, int r, int c) {
-    const int o = (g.nb0 >= 3 && (g.nb0 & 1)) ? 1 : 0;
-    return g.toep > 0 && r > c && c >= o && (r + 1) * NB <= g.n_real;
-}
 
 struct ChunkPtrs {
     double       *L;      // [Bc][(n0 + naux_pad) x n0] factor + aux rows, row-major
@@ -218,6 +206,11 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
 inline int grad_contract_split(long ntri, long Bc) {
     return ntri * Bc <= 1024 ? 4 : (ntri * Bc <= 2048 ? 2 : 1);
 }
+void launch_toep_grad(const JobGeom &g, const ChunkPtrs &p, const double *A, double *wbuf,
+                      const double *quad, double *partials, double *grad, double *logml, int Bc,
+                      const DevSpec &sp, hipStream_t s, const int32_t *items = nullptr,
+                      const int32_t *bucket_counts = nullptr);
+void launch_toep_quad(const JobGeom &g, const double *L, double *quad, int Bc, hipStream_t s);
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s);
 void launch_epilogue(const JobGeom &g, const EpiPtrs &p, const DevSpec &sp, hipStream_t s);
 void launch_cov(const DevProgram *progs, int B, const double *t1, int n1, const double *t2,

@@ -449,11 +449,6 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
         }
         aux = true;
     }
-    if constexpr (GRADJOB) {
-        // Toeplitz gradient jobs: the tiles of one-leaf stationary trees that a fat step touches
-        // first are never stored (the column kernels take them from the leaf's table)
-        if (!aux && grad_tile_unstored(g, r, c) && prog_structure_grad(&P)) return;
-    }
     // thread = (column pair tx, 8-row group ty): two adjacent columns per thread -> 16-byte stores
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int col = c * NB + 2 * tx;
@@ -500,6 +495,9 @@ __global__ __launch_bounds__(256) void fill_lattice_kernel(JobGeom g, ChunkPtrs 
             } else if (ar == naux_t) {
                 v.x = y0[col];
                 v.y = y0[col + 1];
+            } else if (g.aux_e1 && ar == naux_t + 1) {   // the Toeplitz gradient path: e_1' beside y'
+                v.x = (col == 0) ? 1.0 : 0.0;
+                v.y = 0.0;
             } else {
                 v.x = 0.0;
                 v.y = 0.0;
@@ -1984,7 +1982,12 @@ __device__ __forceinline__ void static_for_down(F &&f) {
 // nodes but accumulating only the leaves / binaries with ordinal in [PASS NACC, (PASS + 1) NACC) — the
 // first pass writes the partial sums, the later ones add theirs (same thread, same address, stream
 // order).  Twice the sweep arithmetic, still no scratch.
-template <int NL, int NACC = NL, int PASS = 0>
+// DIAG (the Toeplitz gradient path, stationary trees on a regular series): the contraction runs
+// over the n lattice distances instead of the n^2 / 2 elements — element d stands for the whole
+// d-th diagonal, `Kinv` then holds its weight w[item][d] = sum_i (a_i a_(i-d) - Kinv_(i,i-d)) (the
+// diagonal d = 0 already halved; toep_weights_kernel), evaluated at (row, col) = (d, 0); one
+// distance per thread, blockIdx.x = block of 256 distances.
+template <int NL, int NACC = NL, int PASS = 0, bool DIAG = false>
 __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, ChunkPtrs p,
                                                                   const double *Kinv,
                                                                   const double *alpha,
@@ -2041,12 +2044,15 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
         }
     }
     __syncthreads();
-    int r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-    while ((r + 1) * (r + 2) / 2 <= tile) ++r;
-    while (r * (r + 1) / 2 > tile) --r;
-    const int c = tile - r * (r + 1) / 2;
+    int r = 0, c = 0;
+    if constexpr (!DIAG) {
+        r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+        while (r * (r + 1) / 2 > tile) --r;
+        c = tile - r * (r + 1) / 2;
+    }
     const int tx = tid & 63, ty = tid >> 6;
-    const int col = c * NB + tx;
+    const int col = DIAG ? 0 : c * NB + tx;
     const int np = P.n_params;
     const int nops = __builtin_amdgcn_readfirstlane(P.n_ops);
     const int nl = (nops + 1) / 2, nbin = nops / 2;       // a binary tree: nl leaves, nl - 1 binaries
@@ -2068,20 +2074,25 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     for (int l = 0; l < NACC; ++l) ga[l][0] = ga[l][1] = ga[l][2] = gcp[l][0] = gcp[l][1] = 0.0;
     constexpr auto own = [](int ordinal) { return ordinal / NACC == PASS; };
     double gnoise = 0.0;
-    const double *Ki = Kinv + (long)item * g.n0 * g.n0;
+    const double *Ki = Kinv + (long)item * g.n0 * (DIAG ? 1 : g.n0);
     const double *al = alpha + (long)item * g.n0;
     if (col < g.n_real) {
-        const double t2 = p.t0[col], ac = al[col];
+        const double t2 = p.t0[col], ac = DIAG ? 0.0 : al[col];
         const int q2 = p.qpts[col];
-        for (int rr = 0; rr < nrows; ++rr) {
-            const int row = r * NB + ty * 16 + sub * nrows + rr;
+        for (int rr = 0; rr < (DIAG ? 1 : nrows); ++rr) {
+            const int row = DIAG ? (int)blockIdx.x * 256 + tid : r * NB + ty * 16 + sub * nrows + rr;
             if (row >= g.n_real || col > row) continue;
             // nothing loop-invariant is to be hoisted out of this loop: with the sweeps unrolled
             // hipcc would keep every node's parameters, constants and table addresses in VGPRs
             // across the rows
             asm volatile("" ::: "memory");
-            double w = al[row] * ac - Ki[(long)row * g.n0 + col];
-            if (row == col) w *= 0.5;
+            double w;
+            if constexpr (DIAG) {
+                w = Ki[row];
+            } else {
+                w = al[row] * ac - Ki[(long)row * g.n0 + col];
+                if (row == col) w *= 0.5;
+            }
             const double t1 = p.t0[row];
             const double d = fabs(t1 - t2);
             const int dq = abs(p.qpts[row] - q2);
@@ -2257,6 +2268,57 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
         if (PASS == 0) *dst = sum;
         else *dst += sum;      // a parameter of another pass adds 0.0: its bits do not change
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// The Toeplitz gradient path (stationary trees on a regular series).
+// K is symmetric positive definite Toeplitz there, dK/dtheta depends on the lattice distance only,
+// so  d logml / d theta = sum_d w(d) dk(d)/dtheta  with  w(d) = sum_i (a_i a_(i-d) - Kinv_(i,i-d))
+// (halved at d = 0), and by the Gohberg-Semencul formula the diagonal sums of Kinv follow from its
+// first column x = Kinv e_1 alone:
+//     sum_i Kinv_(i,i-d) = (1/x_0) sum_(m=0)^(n-1-d) (n - d - m) (x_(m+d) x_m - x_(n-m) x_(n-m-d)),  x_n = 0.
+// A = X Kinv for the two aux rows X = [y' ; e_1'] comes out of the ordinary factorisation and one
+// backward sweep (aux_back_*): row 0 = a' (alpha), row 1 = x'.  n^3/3 flops instead of n^3, no W,
+// no Kinv.  One workgroup per (item, block of 256 distances): each thread sums its distance in a
+// fixed order (deterministic).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void toep_weights_kernel(JobGeom g, const double *A, double *wbuf) {
+    extern __shared__ double sh[];      // a[n] | x[n + 1]
+    const int item = blockIdx.y, n = g.n_real, tid = threadIdx.x;
+    const double *a_g = A + (long)item * g.naux_pad * g.ld, *x_g = a_g + g.ld;
+    double *a = sh, *x = sh + n;
+    for (int i = tid; i < n; i += 256) {
+        a[i] = a_g[i];
+        x[i] = x_g[i];
+    }
+    if (tid == 0) x[n] = 0.0;
+    __syncthreads();
+    const int d = blockIdx.x * 256 + tid;
+    if (d >= n) return;
+    const double rx0 = 1.0 / x[0];
+    double sa = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int m = 0; m < n - d; ++m) {
+        const double wgt = (double)(n - d - m);
+        sa += a[m + d] * a[m];
+        s1 += wgt * (x[m + d] * x[m]);
+        s2 += wgt * (x[n - m] * x[n - m - d]);
+    }
+    const double wv = sa - (s1 - s2) * rx0;
+    wbuf[(long)item * g.n0 + d] = (d == 0) ? 0.5 * wv : wv;
+}
+
+// quad = z'z from the aux row that carries y' (row 0), before the backward sweep overwrites it
+__global__ __launch_bounds__(256) void toep_quad_kernel(JobGeom g, const double *L, double *quad) {
+    __shared__ double red[4];
+    const int item = blockIdx.x, tid = threadIdx.x;
+    const double *z = L + (long)item * g.item_stride + (long)g.n0 * g.ld;
+    double s = 0.0;
+    for (int i = tid; i < g.n_real; i += 256) s += z[i] * z[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) quad[item] = red[0] + red[1] + red[2] + red[3];
 }
 
 __global__ __launch_bounds__(128) void grad_reduce_kernel(JobGeom g, const DevProgram *progs,
@@ -2701,6 +2763,49 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
     }
     hipLaunchKernelGGL(grad_reduce_kernel, dim3(Bc), dim3(128), 0, s0, g, p.progs, partials, quad,
                        p.logdet, grad, logml, nparts);
+}
+
+// The Toeplitz gradient path after the factorisation and the backward sweep: weights per distance
+// from A = [a' ; x'], then the 1-D contraction (DIAG instantiations, by tree-size bucket) and the
+// final sum.  items / bucket_counts as in launch_grad_contract (null: one launch sized by maxops).
+void launch_toep_grad(const JobGeom &g, const ChunkPtrs &p, const double *A, double *wbuf,
+                      const double *quad, double *partials, double *grad, double *logml, int Bc,
+                      const DevSpec &sp, hipStream_t s, const int32_t *items,
+                      const int32_t *bucket_counts) {
+    const int nd = (g.n_real + 255) / 256;
+    const size_t lds = sizeof(double) * (2 * (size_t)g.n_real + 1);   // <= 128 KiB: n <= 8192 (ngp_grad_stage)
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)toep_weights_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(toep_weights_kernel, dim3(nd, Bc), dim3(256), lds, s, g, A, wbuf);
+    int32_t whole[GRAD_BUCKETS] = {};
+    whole[grad_bucket(g.maxops)] = Bc;
+    const int32_t *cnt = items ? bucket_counts : whole;
+    const int32_t *it = items;
+    for (int bk = 0; bk < GRAD_BUCKETS; ++bk) {
+        const int nb = cnt[bk];
+        if (nb <= 0) continue;
+        const dim3 grid(nd, nb), blk(256);
+#define NGP_LAUNCH_DIAG(...)                                                                     \
+    hipLaunchKernelGGL((grad_contract_lists_kernel<__VA_ARGS__, true>), grid, blk, 0, s, g, p, wbuf, \
+                       wbuf, partials, nd, 1, sp, it)
+        if (bk == 0) NGP_LAUNCH_DIAG(1, 1, 0);
+        else if (bk == 1) NGP_LAUNCH_DIAG(2, 2, 0);
+        else if (bk == 2) NGP_LAUNCH_DIAG(4, 4, 0);
+        else if (bk == 3) NGP_LAUNCH_DIAG(8, 8, 0);
+        else {   // 9 .. 32 leaves: passes of eight accumulator sets (NGP_MAX_OPS = 64 nodes)
+            NGP_LAUNCH_DIAG(16, 8, 0);
+            NGP_LAUNCH_DIAG(16, 8, 1);
+        }
+#undef NGP_LAUNCH_DIAG
+        if (it) it += nb;
+    }
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(Bc), dim3(128), 0, s, g, p.progs, partials, quad,
+                       p.logdet, grad, logml, nd);
+}
+
+void launch_toep_quad(const JobGeom &g, const double *L, double *quad, int Bc, hipStream_t s) {
+    hipLaunchKernelGGL(toep_quad_kernel, dim3(Bc), dim3(256), 0, s, g, L, quad);
 }
 
 void launch_gram(const JobGeom &g, const double *L, double *G, int Bc, hipStream_t s) {
