@@ -359,7 +359,12 @@ typedef struct ngp_profile {
  * from those numbers in LDS where it would have read the stored tile.  The values are the table
  * entries the fill would have stored, so every result is bit-identical with the option off
  * (tests/test_structured_storage_gpu.py); off exists for that comparison and for A/B timing.
- * Applies to jobs staged after the call.                                                        */
+ * The same switch governs the Toeplitz gradient path of gradient jobs (ngp_logml_grad_batch,
+ * ngp_grad_stage): on a regular series the items whose trees are stationary are evaluated from the
+ * Cholesky factor alone — the diagonal sums of K^-1 that the gradient needs follow from its first
+ * column (Gohberg-Semencul), n^3/3 flops instead of n^3.  That is other arithmetic, not other
+ * storage: logml and gradients agree with the general path to rounding (1e-11 on gradients in the
+ * tests), not bit for bit.  Applies to jobs staged after the call.                              */
 ngp_status ngp_set_structured_storage(ngp_ctx *ctx, int32_t on);
 
 ngp_status ngp_profile_enable(ngp_ctx *ctx, int32_t on);
