@@ -1882,38 +1882,39 @@ ngp_status grad_leaf_set_params(GradLeaf *j, const double *params, const double 
     return NGP_OK;
 }
 
-ngp_status grad_leaf_run(GradLeaf *j, double *logml, double *grad, int32_t *info) {
-    if (!j || !grad) return NGP_ERR_ARG;
-    ngp_ctx *c = j->ctx;
-    const JobGeom &g = j->g;
-    const int B = j->B;
-    const int GP = NGP_MAX_PARAMS + 1;
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const DevSpec sp = dev_spec(j->spec);
-    const int ntri = g.nb0 * (g.nb0 + 1) / 2;
-    auto freeall = [] {};   // the working storage is the context's workspace: nothing to give back
-    const size_t l_bytes = (size_t)g.item_stride * 8;
-    const size_t tab_bytes = g.lattice ? 8 * (size_t)g.maxstat * g.R : 0;
-    const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
-    const bool tp = j->toep_path;
-    const int nd = (g.n_real + 255) / 256;          // Toeplitz path: blocks of 256 lattice distances
-    const size_t aux_bytes = 8 * (size_t)g.naux_pad * g.n0;
-    const size_t item_bytes =
-        tp ? l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)NB * NB * g.nb0 + aux_bytes +
-                 8 * (size_t)g.n0 + 8 * (size_t)nd * GP
-           : l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 + 8 * (size_t)g.n0 +
-                 8 * (size_t)ntri * GP;
-    if ((size_t)B * item_bytes > c->mem_cap) c->refresh_mem_cap();   // large job: today's figure
-    int Bc = (int)std::min<size_t>(std::min<size_t>((size_t)B, MAX_CHUNK_ITEMS),
-                                   std::max<size_t>(1, c->mem_cap / item_bytes));
-    void *d_L, *d_dinv, *d_tab = nullptr, *d_sig = nullptr, *d_dtab = nullptr, *d_kinv,
-         *d_alpha, *d_quad, *d_part, *d_items;
-    std::vector<int32_t> h_items((size_t)B);   // alive until the stream is synchronised below
-    ngp_status st;
-    // the chunk is halved when the device cannot hold it after all (other handles, rounding)
-    auto take_all = [&](WsPlan &dalloc) -> ngp_status {
+// One evaluation of a leaf in three steps, so that two leaves of a small batch can be in flight side
+// by side (grad_pair_run): lay the working storage out in the context's workspace, enqueue
+// everything on a lane's streams (upload of new parameters ... results on their way back), and,
+// after the lane has been synchronised, unpack.
+struct LeafRun {
+    GradLeaf *j = nullptr;
+    int Bc = 0;
+    void *d_L = nullptr, *d_dinv = nullptr, *d_tab = nullptr, *d_sig = nullptr, *d_dtab = nullptr,
+         *d_kinv = nullptr, *d_alpha = nullptr, *d_quad = nullptr, *d_part = nullptr, *d_items = nullptr;
+    std::vector<int32_t> h_items;   // alive until the lane is synchronised
+    double *splitk = nullptr;       // pair runs: the context's split-k buffer for this leaf's value kernels
+
+    size_t item_bytes() const {
+        const JobGeom &g = j->g;
+        const int GP = NGP_MAX_PARAMS + 1, ntri = g.nb0 * (g.nb0 + 1) / 2, nd = (g.n_real + 255) / 256;
+        const size_t l_bytes = (size_t)g.item_stride * 8;
+        const size_t tab_bytes = g.lattice ? 8 * (size_t)g.maxstat * g.R : 0;
+        const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
+        const size_t aux_bytes = 8 * (size_t)g.naux_pad * g.n0;
+        return j->toep_path ? l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)NB * NB * g.nb0 + aux_bytes +
+                                  8 * (size_t)g.n0 + 8 * (size_t)nd * GP
+                            : l_bytes + 4 * tab_bytes + sig_bytes + 8 * (size_t)g.n0 * g.n0 +
+                                  8 * (size_t)g.n0 + 8 * (size_t)ntri * GP;
+    }
+    // the working buffers of a chunk of Bc items, requested from `dalloc` (measured, then taken)
+    ngp_status layout(WsPlan &dalloc) {
+        const JobGeom &g = j->g;
+        const bool tp = j->toep_path;
+        const int GP = NGP_MAX_PARAMS + 1, ntri = g.nb0 * (g.nb0 + 1) / 2, nd = (g.n_real + 255) / 256;
+        const size_t l_bytes = (size_t)g.item_stride * 8;
+        const size_t tab_bytes = g.lattice ? 8 * (size_t)g.maxstat * g.R : 0;
+        const size_t sig_bytes = g.lattice ? 8 * (size_t)g.maxcp * g.npts : 0;
+        const size_t aux_bytes = 8 * (size_t)g.naux_pad * g.n0;
         ngp_status r;
         (void)((r = dalloc(&d_L, l_bytes * (size_t)Bc)) ||
                // the Toeplitz path keeps every block inverse M_j for its backward sweep
@@ -1930,130 +1931,210 @@ ngp_status grad_leaf_run(GradLeaf *j, double *logml, double *grad, int32_t *info
                            tp ? 8 * (size_t)Bc * nd * GP
                               : 8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc),
                                                      4096) * GP)) ||
-               (r = dalloc(&d_items, 4 * (size_t)B)));
+               (r = dalloc(&d_items, 4 * (size_t)j->B)));
         return r;
-    };
-    for (;; Bc = (Bc + 1) / 2) {
-        WsPlan measure{c, true}, take{c, false};
-        (void)take_all(measure);
-        st = c->ws_reserve(measure.total);
-        if (!st) st = take_all(take);
-        if (!st) break;
-        if (st != NGP_ERR_TOO_LARGE || Bc <= 1) return st;
     }
-    unsigned char *const io = j->io;
-    void *const d_prog = io, *const d_t = io + j->o_t, *const d_y = io + j->o_y,
-                *const d_q = g.lattice ? io + j->o_q : nullptr, *const d_info = io + j->o_info,
-                *const d_logdet = io + j->o_logdet, *const d_grad = io + j->o_grad,
-                *const d_logml = io + j->o_logml;
-    hipError_t e = hipSuccess;
-    if (j->progs_dirty)   // new parameters for the same trees: the programs go up again, nothing else
-        e = hipMemcpyAsync(d_prog, j->hp.data(), sizeof(DevProgram) * (size_t)B,
-                           hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && !j->fresh)   // a re-run: info | logdet are contiguous in the arena
-        e = hipMemsetAsync(d_info, 0, j->o_grad - j->o_info, s);
-    if (e != hipSuccess) { freeall(); return (ngp_status)e; }
-    j->progs_dirty = false;
-    j->fresh = false;
-    EventTimer tm(c->profiling, s);
-    for (int b0 = 0; b0 < B; b0 += Bc) {
-        const int bc = std::min(Bc, B - b0);
-        ChunkPtrs p{};
-        p.L = (double *)d_L;
-        p.dinv = (double *)d_dinv;
-        p.progs = (const DevProgram *)d_prog + b0;
-        p.t0 = (const double *)d_t;
-        p.taux = (const double *)d_t;
-        p.y0 = (const double *)d_y + (g.y_shared ? 0 : (int64_t)b0 * g.n0);
-        p.logdet = (double *)d_logdet + b0;
-        p.info = (int32_t *)d_info + b0;
-        p.tab = (double *)d_tab;
-        p.sig = (double *)d_sig;
-        p.qpts = (const int32_t *)d_q;
-        p.dtab = (double *)d_dtab;
-        if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
-        // K's lower blocks, the y' tile row and the zero blocks (a, a-1): the identity block of
-        // the aux rows is synthesised by the column kernels, not written
-        tm.run(4, 0.0, 8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + (tp ? 1.0 : 2.0) * NB * (double)g.n0),
-               [&] { launch_fill(g, p, bc, sp, s); });
-        const size_t mstep = tp ? (size_t)bc * NB * NB : 0;
-        factor_chunk(lane_of(c), g, p, bc, tm, mstep);
-        const double n3 = (double)g.n0 * g.n0 * g.n0;
-        if (tp) {
-            // z'z, then A = X K^-1 by one backward sweep of the two aux rows (class 10 with the
-            // other backward sweeps of the library)
-            tm.run(10, 0.0, bc * 8.0 * g.n0, [&] { launch_toep_quad(g, (const double *)d_L, (double *)d_quad, bc, s); });
-            for (int cc = g.nb0 - 1; cc >= 0; --cc)
-                tm.run(10, bc * 2.0 * 2.0 * NB * (double)(cc + 1) * NB,
-                       bc * 8.0 * ((double)NB * NB * (cc + 1) + 2.0 * 2.0 * NB * (cc + 1)), [&] {
-                           launch_aux_back(g, p, p.dinv, mstep, (double *)d_kinv, 0, bc, cc, s);
-                       });
-        } else {
-            tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
-                launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
-                                 (double *)d_quad, bc, s, c->side, c->ev_fork, c->ev_join);
-            });
-        }
-        // the chunk's items sorted by tree size: every size class runs on the contraction kernel
-        // sized for it
-        // (small launches — the 24- or 64-particle calls of a fit on short series — stay ONE launch
-        // sized by the largest tree: up to five dependent launches of a few microseconds each cost
-        // more there than the occupancy of the smaller instantiations gains)
-        const bool by_size = g.lattice && (tp ? (long)nd * bc > 512 : (long)ntri * bc > 4096);
-        int32_t counts[GRAD_BUCKETS] = {};
-        if (by_size) {
-            for (int i = 0; i < bc; ++i) ++counts[grad_bucket(j->n_ops[(size_t)(b0 + i)])];
-            int32_t pos[GRAD_BUCKETS], acc = 0;
-            for (int k = 0; k < GRAD_BUCKETS; ++k) { pos[k] = acc; acc += counts[k]; }
-            for (int i = 0; i < bc; ++i)
-                h_items[(size_t)b0 + (size_t)pos[grad_bucket(j->n_ops[(size_t)(b0 + i)])]++] = i;
-            const hipError_t ce = hipMemcpyAsync((int32_t *)d_items + b0, h_items.data() + b0,
-                                                 4 * (size_t)bc, hipMemcpyHostToDevice, s);
-            if (ce != hipSuccess) {
-                (void)hipStreamSynchronize(s);
-                tm.resolve(c->prof);
-                freeall();
-                return (ngp_status)ce;
+
+    // everything of the evaluation on the lane's streams; the caller synchronises ln.main
+    ngp_status launch(const Lane &ln, EventTimer &tm, bool no_lane_split) {
+        ngp_ctx *c = j->ctx;
+        const JobGeom &g = j->g;
+        const int B = j->B;
+        const bool tp = j->toep_path;
+        const int GP = NGP_MAX_PARAMS + 1, ntri = g.nb0 * (g.nb0 + 1) / 2, nd = (g.n_real + 255) / 256;
+        hipStream_t s = ln.main;
+        const DevSpec sp = dev_spec(j->spec);
+        h_items.assign((size_t)B, 0);
+        unsigned char *const io = j->io;
+        void *const d_prog = io, *const d_t = io + j->o_t, *const d_y = io + j->o_y,
+                    *const d_q = g.lattice ? io + j->o_q : nullptr, *const d_info = io + j->o_info,
+                    *const d_logdet = io + j->o_logdet, *const d_grad = io + j->o_grad,
+                    *const d_logml = io + j->o_logml;
+        hipError_t e = hipSuccess;
+        if (j->progs_dirty)   // new parameters for the same trees: the programs go up again, nothing else
+            e = hipMemcpyAsync(d_prog, j->hp.data(), sizeof(DevProgram) * (size_t)B,
+                               hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && !j->fresh)   // a re-run: info | logdet are contiguous in the arena
+            e = hipMemsetAsync(d_info, 0, j->o_grad - j->o_info, s);
+        if (e != hipSuccess) return (ngp_status)e;
+        j->progs_dirty = false;
+        j->fresh = false;
+        for (int b0 = 0; b0 < B; b0 += Bc) {
+            const int bc = std::min(Bc, B - b0);
+            ChunkPtrs p{};
+            p.L = (double *)d_L;
+            p.dinv = (double *)d_dinv;
+            p.progs = (const DevProgram *)d_prog + b0;
+            p.t0 = (const double *)d_t;
+            p.taux = (const double *)d_t;
+            p.y0 = (const double *)d_y + (g.y_shared ? 0 : (int64_t)b0 * g.n0);
+            p.logdet = (double *)d_logdet + b0;
+            p.info = (int32_t *)d_info + b0;
+            p.tab = (double *)d_tab;
+            p.sig = (double *)d_sig;
+            p.qpts = (const int32_t *)d_q;
+            p.dtab = (double *)d_dtab;
+            p.splitk_part = splitk;
+            if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
+            // K's lower blocks, the y' tile row and the zero blocks (a, a-1): the identity block of
+            // the aux rows is synthesised by the column kernels, not written
+            tm.run(4, 0.0,
+                   8.0 * bc * ((double)g.n0 * (g.n0 + NB) / 2.0 + (tp ? 1.0 : 2.0) * NB * (double)g.n0),
+                   [&] { launch_fill(g, p, bc, sp, s); });
+            const size_t mstep = tp ? (size_t)bc * NB * NB : 0;
+            factor_chunk(ln, g, p, bc, tm, mstep, nullptr, nullptr, nullptr, no_lane_split);
+            const double n3 = (double)g.n0 * g.n0 * g.n0;
+            if (tp) {
+                // z'z, then A = X K^-1 by one backward sweep of the two aux rows (class 10 with the
+                // other backward sweeps of the library)
+                tm.run(10, 0.0, bc * 8.0 * g.n0,
+                       [&] { launch_toep_quad(g, (const double *)d_L, (double *)d_quad, bc, s); });
+                for (int cc = g.nb0 - 1; cc >= 0; --cc)
+                    tm.run(10, bc * 2.0 * 2.0 * NB * (double)(cc + 1) * NB,
+                           bc * 8.0 * ((double)NB * NB * (cc + 1) + 2.0 * 2.0 * NB * (cc + 1)), [&] {
+                               launch_aux_back(g, p, p.dinv, mstep, (double *)d_kinv, 0, bc, cc, s);
+                           });
+            } else {
+                tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
+                    launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
+                                     (double *)d_quad, bc, s, ln.side, ln.fork, ln.join);
+                });
+            }
+            // the chunk's items sorted by tree size: every size class runs on the contraction kernel
+            // sized for it
+            // (small launches — the 24- or 64-particle calls of a fit on short series — stay ONE launch
+            // sized by the largest tree: up to five dependent launches of a few microseconds each cost
+            // more there than the occupancy of the smaller instantiations gains)
+            const bool by_size = g.lattice && (tp ? (long)nd * bc > 512 : (long)ntri * bc > 4096);
+            int32_t counts[GRAD_BUCKETS] = {};
+            if (by_size) {
+                for (int i = 0; i < bc; ++i) ++counts[grad_bucket(j->n_ops[(size_t)(b0 + i)])];
+                int32_t pos[GRAD_BUCKETS], acc = 0;
+                for (int k = 0; k < GRAD_BUCKETS; ++k) { pos[k] = acc; acc += counts[k]; }
+                for (int i = 0; i < bc; ++i)
+                    h_items[(size_t)b0 + (size_t)pos[grad_bucket(j->n_ops[(size_t)(b0 + i)])]++] = i;
+                const hipError_t ce = hipMemcpyAsync((int32_t *)d_items + b0, h_items.data() + b0,
+                                                     4 * (size_t)bc, hipMemcpyHostToDevice, s);
+                if (ce != hipSuccess) return (ngp_status)ce;
+            }
+            if (tp) {
+                tm.run(11, 0.0, bc * 8.0 * 3.0 * (double)g.n0, [&] {
+                    launch_toep_grad(g, p, (const double *)d_kinv, (double *)d_alpha,
+                                     (const double *)d_quad, (double *)d_part,
+                                     (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc, sp,
+                                     s, by_size ? (const int32_t *)d_items + b0 : nullptr, counts);
+                });
+            } else {
+                tm.run(11, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
+                    launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
+                                         (const double *)d_quad, (double *)d_part,
+                                         (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0,
+                                         bc, sp, s, by_size ? (const int32_t *)d_items + b0 : nullptr,
+                                         counts, ln.side, ln.fork, ln.join);
+                });
             }
         }
-        if (tp) {
-            tm.run(11, 0.0, bc * 8.0 * 3.0 * (double)g.n0, [&] {
-                launch_toep_grad(g, p, (const double *)d_kinv, (double *)d_alpha, (const double *)d_quad,
-                                 (double *)d_part, (double *)d_grad + (int64_t)b0 * GP,
-                                 (double *)d_logml + b0, bc, sp, s,
-                                 by_size ? (const int32_t *)d_items + b0 : nullptr, counts);
-            });
-        } else {
-            tm.run(11, 0.0, bc * 8.0 * 0.5 * (double)g.n0 * g.n0, [&] {
-                launch_grad_contract(g, p, (const double *)d_kinv, (const double *)d_alpha,
-                                     (const double *)d_quad, (double *)d_part,
-                                     (double *)d_grad + (int64_t)b0 * GP, (double *)d_logml + b0, bc,
-                                     sp, s, by_size ? (const int32_t *)d_items + b0 : nullptr, counts,
-                                     c->side, c->ev_fork, c->ev_join);
-            });
+        e = hipMemcpyAsync(j->h_out.data(), d_info, j->h_out.size(), hipMemcpyDeviceToHost, s);
+        return e == hipSuccess ? NGP_OK : (ngp_status)e;
+    }
+
+    // after the lane is synchronised: device parameter order -> caller's order; d/d noise last
+    void unpack(double *logml, double *grad, int32_t *info) {
+        const int GP = NGP_MAX_PARAMS + 1;
+        if (!j->h_in.empty()) std::vector<unsigned char>().swap(j->h_in);   // the staging copy has left it
+        const int32_t *h_info = (const int32_t *)j->h_out.data();
+        const double *h_grad = (const double *)(j->h_out.data() + (j->o_grad - j->o_info)),
+                     *h_lm = (const double *)(j->h_out.data() + (j->o_logml - j->o_info));
+        size_t off = 0;
+        for (int i = 0; i < j->B; ++i) {
+            const int np = j->n_params[(size_t)i];
+            for (int k = 0; k < np; ++k)
+                grad[off + (size_t)j->perm[(size_t)i][(size_t)k]] = h_grad[(size_t)i * GP + (size_t)k];
+            grad[off + (size_t)np] = h_grad[(size_t)i * GP + (size_t)np];
+            off += (size_t)np + 1;
+            if (logml) logml[i] = h_lm[(size_t)i];
+            if (info) info[i] = h_info[(size_t)i];
         }
     }
-    e = hipMemcpyAsync(j->h_out.data(), d_info, j->h_out.size(), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+};
+
+ngp_status grad_leaf_run(GradLeaf *j, double *logml, double *grad, int32_t *info) {
+    if (!j || !grad) return NGP_ERR_ARG;
+    ngp_ctx *c = j->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    LeafRun r;
+    r.j = j;
+    const size_t item_bytes = r.item_bytes();
+    if ((size_t)j->B * item_bytes > c->mem_cap) c->refresh_mem_cap();   // large job: today's figure
+    r.Bc = (int)std::min<size_t>(std::min<size_t>((size_t)j->B, MAX_CHUNK_ITEMS),
+                                 std::max<size_t>(1, c->mem_cap / item_bytes));
+    // the chunk is halved when the device cannot hold it after all (other handles, rounding)
+    for (;; r.Bc = (r.Bc + 1) / 2) {
+        WsPlan measure{c, true}, take{c, false};
+        (void)r.layout(measure);
+        ngp_status st = c->ws_reserve(measure.total);
+        if (!st) st = r.layout(take);
+        if (!st) break;
+        if (st != NGP_ERR_TOO_LARGE || r.Bc <= 1) return st;
+    }
+    EventTimer tm(c->profiling, c->stream);
+    ngp_status st = r.launch(lane_of(c), tm, false);
+    hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipGetLastError();
     tm.resolve(c->prof);
-    freeall();
-    if (!j->h_in.empty()) std::vector<unsigned char>().swap(j->h_in);   // the staging copy has left it
+    if (st) return st;
     if (e != hipSuccess) return (ngp_status)e;
-    // device parameter order -> caller's order; d/d noise last
-    const int32_t *h_info = (const int32_t *)j->h_out.data();
-    const double *h_grad = (const double *)(j->h_out.data() + (j->o_grad - j->o_info)),
-                 *h_lm = (const double *)(j->h_out.data() + (j->o_logml - j->o_info));
-    size_t off = 0;
-    for (int i = 0; i < B; ++i) {
-        const int np = j->n_params[(size_t)i];
-        for (int k = 0; k < np; ++k)
-            grad[off + (size_t)j->perm[(size_t)i][(size_t)k]] = h_grad[(size_t)i * GP + (size_t)k];
-        grad[off + (size_t)np] = h_grad[(size_t)i * GP + (size_t)np];
-        off += (size_t)np + 1;
-        if (logml) logml[i] = h_lm[(size_t)i];
-        if (info) info[i] = h_info[(size_t)i];
-    }
+    r.unpack(logml, grad, info);
+    return NGP_OK;
+}
+
+// The two leaves of a SMALL mixed batch side by side, each on its own pair of streams (the lanes of
+// the two-lane sweep): one after the other they are two chains of dependent launches where the
+// unsplit batch is one (64 items at n = 2048: 16.3 ms against 15.3).  Both as single chunks in one
+// workspace reservation; NGP_ERR_TOO_LARGE if that does not fit (the caller then runs them in turn).
+ngp_status grad_pair_run(GradLeaf *a, double *lm_a, double *g_a, int32_t *info_a, GradLeaf *b,
+                         double *lm_b, double *g_b, int32_t *info_b) {
+    ngp_ctx *c = a->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->make_lanes(2)) return NGP_ERR_TOO_LARGE;
+    LeafRun ra, rb;
+    ra.j = a;
+    rb.j = b;
+    ra.Bc = a->B;
+    rb.Bc = b->B;
+    WsPlan measure{c, true}, take{c, false};
+    (void)ra.layout(measure);
+    (void)rb.layout(measure);
+    if (measure.total > c->mem_cap) c->refresh_mem_cap();
+    if (measure.total > c->mem_cap) return NGP_ERR_TOO_LARGE;
+    ngp_status st = c->ws_reserve(measure.total);
+    if (st) return st;
+    if ((st = ra.layout(take)) || (st = rb.layout(take))) return st;
+    // the Toeplitz leaf runs on the value kernels: their split-k fat steps of late columns (small
+    // chunks) need the context's buffer, which factor_chunk only reserves for a chunk it owns whole
+    if (b->toep_path && b->g.nb0 >= 8 && b->B <= AHEAD_EARLY_MAX_ITEMS && c->splitk_reserve(b->B) == NGP_OK)
+        rb.splitk = c->splitk_part;
+    const Lane l0 = lane_of(c);
+    const Lane l1{c->lane_main[1], c->lane_side[1], c->lane_fork[1], c->lane_join[1], c};
+    // what the context's stream holds (the staging copies of both leaves) comes first on lane 1 too
+    (void)hipEventRecord(c->ev_lane_go, c->stream);
+    (void)hipStreamWaitEvent(l1.main, c->ev_lane_go, 0);
+    EventTimer tma(c->profiling, l0.main), tmb(c->profiling, l1.main);
+    ngp_status sa = ra.launch(l0, tma, true);
+    ngp_status sb = rb.launch(l1, tmb, true);
+    hipError_t e = hipStreamSynchronize(l0.main);
+    const hipError_t e1 = hipStreamSynchronize(l1.main);
+    if (e == hipSuccess) e = e1;
+    if (e == hipSuccess) e = hipGetLastError();
+    tma.resolve(c->prof);
+    tmb.resolve(c->prof);
+    if (sa) return sa;
+    if (sb) return sb;
+    if (e != hipSuccess) return (ngp_status)e;
+    ra.unpack(lm_a, g_a, info_a);
+    rb.unpack(lm_b, g_b, info_b);
     return NGP_OK;
 }
 
@@ -2080,8 +2161,9 @@ struct ngp_grad_job {
     GradLeaf *gen = nullptr, *toep = nullptr;
     std::vector<int32_t> idx_gen, idx_toep;     // leaf item -> caller's item
     std::vector<size_t> poff, goff;             // [B + 1] offsets of an item's parameters / gradient
-    std::vector<double> buf_p, buf_n, buf_lm, buf_g;
-    std::vector<int32_t> buf_info;
+    std::vector<double> buf_p, buf_n, buf_lm, buf_g, buf_lm2, buf_g2;
+    std::vector<int32_t> buf_info, buf_info2;
+    bool side_by_side = false;                  // a small split batch: both leaves in flight together
 };
 
 extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
@@ -2136,11 +2218,21 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
     // 2,615 -> 1,794 ms) and costs when they are latency-bound (24 items at n = 208: 615 -> 790 us; 64 at
     // n = 2048: 15.9 -> 16.3 ms), so a mixed batch is split only from SPLIT_MIN_ITEMS on; a batch
     // of stationary trees only is never split and always takes the Toeplitz path.
-    constexpr int SPLIT_MIN_ITEMS = 256;
+    // Just below that (PAIR_MIN_ITEMS .. SPLIT_MIN_ITEMS, long series) the two leaves run SIDE BY SIDE
+    // on two stream pairs (grad_pair_run); smaller mixed batches are not split at all.  Measured on
+    // the prior ensemble at n = 2048, general job -> split: 64 items 15.1 -> 17.2 ms side by side
+    // (each leaf's chain is as long as the whole batch's, and they compete for the chip), 128 items
+    // 26.8 -> 25.0 side by side, 256 items 50.2 -> 40.0 and 512 items 98.8 -> 72.0 in turn
+    // (scripts/mixed_grad_probe.py).
+    constexpr int SPLIT_MIN_ITEMS = 256, PAIR_MIN_ITEMS = 128, PAIR_MIN_N = 1024;
     if (!j->idx_gen.empty() && !j->idx_toep.empty() && B < SPLIT_MIN_ITEMS) {
-        j->idx_toep.clear();
-        j->idx_gen.resize((size_t)B);
-        for (int i = 0; i < B; ++i) j->idx_gen[(size_t)i] = i;
+        if (n >= PAIR_MIN_N && B >= PAIR_MIN_ITEMS) {
+            j->side_by_side = true;
+        } else {
+            j->idx_toep.clear();
+            j->idx_gen.resize((size_t)B);
+            for (int i = 0; i < B; ++i) j->idx_gen[(size_t)i] = i;
+        }
     }
     auto stage_leaf = [&](const std::vector<int32_t> &idx, bool toep_path, GradLeaf **leaf) -> ngp_status {
         if (idx.empty()) return NGP_OK;
@@ -2187,6 +2279,38 @@ extern "C" ngp_status ngp_grad_job_set_params(ngp_grad_job *j, const double *par
 
 extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *grad, int32_t *info) {
     if (!j || !grad) return NGP_ERR_ARG;
+    auto scatter = [&](const std::vector<int32_t> &idx, const std::vector<double> &lm,
+                       const std::vector<double> &g, const std::vector<int32_t> &inf) {
+        size_t off = 0;
+        for (size_t a = 0; a < idx.size(); ++a) {
+            const size_t i = (size_t)idx[a], len = j->goff[i + 1] - j->goff[i];
+            std::memcpy(grad + j->goff[i], g.data() + off, 8 * len);
+            off += len;
+            if (logml) logml[i] = lm[a];
+            if (info) info[i] = inf[a];
+        }
+    };
+    if (j->side_by_side && j->gen && j->toep) {
+        auto size_bufs = [&](const std::vector<int32_t> &idx, std::vector<double> &lm,
+                             std::vector<double> &g, std::vector<int32_t> &inf) {
+            size_t ng = 0;
+            for (int32_t i : idx) ng += j->goff[(size_t)i + 1] - j->goff[(size_t)i];
+            lm.resize(idx.size());
+            inf.resize(idx.size());
+            g.resize(ng);
+        };
+        size_bufs(j->idx_gen, j->buf_lm, j->buf_g, j->buf_info);
+        size_bufs(j->idx_toep, j->buf_lm2, j->buf_g2, j->buf_info2);
+        const ngp_status st = grad_pair_run(j->gen, j->buf_lm.data(), j->buf_g.data(), j->buf_info.data(),
+                                            j->toep, j->buf_lm2.data(), j->buf_g2.data(),
+                                            j->buf_info2.data());
+        if (st == NGP_OK) {
+            scatter(j->idx_gen, j->buf_lm, j->buf_g, j->buf_info);
+            scatter(j->idx_toep, j->buf_lm2, j->buf_g2, j->buf_info2);
+            return NGP_OK;
+        }
+        if (st != NGP_ERR_TOO_LARGE) return st;   // no room for both at once: one after the other
+    }
     auto run_leaf = [&](GradLeaf *leaf, const std::vector<int32_t> &idx) -> ngp_status {
         if (!leaf) return NGP_OK;
         if ((int)idx.size() == j->B) return grad_leaf_run(leaf, logml, grad, info);
