@@ -774,7 +774,10 @@ def test_resident_gradient_job_equals_the_one_shot_call(ctx):
     parameter set that makes one item's matrix indefinite (reported in info, the others intact)."""
     from nowcastautogp_amd._abi import KernelArray
     rng = np.random.Generator(np.random.PCG64(11))
-    for n, P, per_item in ((150, 5, False), (208, 24, True), (705, 7, True), (1600, 64, False)):
+    # (300, 260): a mixed batch of more than 256 items on a regular series is carried by two leaves —
+    # the parameters are split between them and the results scattered back; (1100, 130): side by side
+    for n, P, per_item in ((150, 5, False), (208, 24, True), (705, 7, True), (1600, 64, False),
+                           (300, 260, True), (1100, 130, False)):
         w = make_workload("C2", n=n, P=P, D=1)
         y = w.y[None, :] + 0.02 * rng.standard_normal((P, n)) if per_item else w.y
         ka = KernelArray(list(w.programs))
