@@ -78,6 +78,46 @@ int main(void) {
               relerr(&grad[off], rg, ks[p].n_params + 1));
     }
 
+    /* --- the same through a resident gradient job: one-shot = stage + run, new parameters ---- */
+    {
+        ngp_grad_job *gj = NULL;
+        st = ngp_grad_stage(ctx, P, ks, N, t, y, 0, &gj);
+        CHECK(st == NGP_OK && gj, "ngp_grad_stage: %s", ngp_strerror(st));
+        if (gj) {
+            double lm2[P], grad2[7 + 8 + 7];
+            st = ngp_grad_job_run(gj, lm2, grad2, info);
+            CHECK(st == NGP_OK, "ngp_grad_job_run: %s", ngp_strerror(st));
+            CHECK(relerr(lm2, lm, P) == 0.0 && relerr(grad2, grad, 7 + 8 + 7) == 0.0,
+                  "the resident job's first run differs from the one-shot call");
+            /* new parameters for the same trees (what a leapfrog step sends), back to the old ones */
+            double flat[6 + 7 + 6], nz[P], flat0[6 + 7 + 6], nz0[P];
+            int o = 0;
+            for (int p = 0; p < P; ++p) {
+                for (int q = 0; q < ks[p].n_params; ++q, ++o) {
+                    flat0[o] = ks[p].params[q];
+                    flat[o] = ks[p].params[q] * 1.01;
+                }
+                nz0[p] = ks[p].noise;
+                nz[p] = ks[p].noise * 0.9;
+            }
+            CHECK(ngp_grad_job_set_params(gj, flat, nz) == NGP_OK, "ngp_grad_job_set_params");
+            CHECK(ngp_grad_job_run(gj, lm2, grad2, info) == NGP_OK, "run with new parameters");
+            CHECK(relerr(lm2, lm, P) > 0.0, "new parameters did not reach the device");
+            CHECK(ngp_grad_job_set_params(gj, flat0, nz0) == NGP_OK, "ngp_grad_job_set_params back");
+            CHECK(ngp_grad_job_run(gj, lm2, grad2, info) == NGP_OK, "run with the old parameters");
+            CHECK(relerr(lm2, lm, P) == 0.0 && relerr(grad2, grad, 7 + 8 + 7) == 0.0,
+                  "the old parameters do not give the old answer");
+            ngp_grad_job_destroy(gj);
+        }
+        /* the storage option: value jobs bit for bit the same without it */
+        double lb3[P], lf3[P * D], mu3[P * D * M], sg3[P * M * M];
+        CHECK(ngp_set_structured_storage(ctx, 0) == NGP_OK, "ngp_set_structured_storage off");
+        st = ngp_nowcast_batch(ctx, P, ks, N, t, y, DD, t_add, D, y_add, M, t_new, 1, lb3, lf3, mu3, sg3, info);
+        CHECK(st == NGP_OK && relerr(lf3, lf, P * D) == 0.0 && relerr(mu3, mu, P * D * M) == 0.0 &&
+              relerr(sg3, sg, P * M * M) == 0.0, "structured storage changes a value job's bits");
+        CHECK(ngp_set_structured_storage(ctx, 1) == NGP_OK, "ngp_set_structured_storage on");
+    }
+
     /* --- resident factor: same answers without refactorising ------------------------------ */
     ngp_factor *f = NULL;
     st = ngp_factor_create(ctx, P, ks, N, t, y, 0, &f);
