@@ -572,6 +572,12 @@ def main():
         args.no_fit = args.no_cpu_baseline = args.no_other_configs = True
     if sharded or grad_mode:
         args.no_fit = args.no_other_configs = True
+    if world > 1:
+        # N > 1: the line is the scaling figure.  The end-to-end legs, the CPU baseline and the other
+        # configurations are single-GPU legs (rank 0 at N = 1 only) — and the host mirror shards
+        # every model as soon as a process group exists, so a fit on rank 0 alone would wait for
+        # peers that have left (found by the two-rank rehearsal of the default command line)
+        args.no_fit = args.no_cpu_baseline = args.no_other_configs = True
     if sharded:
         args.no_cpu_baseline = True      # the step's outputs are draws, not per-item logml's
     shared_ms = cached_ms = f64_ms = None
