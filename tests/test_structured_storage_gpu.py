@@ -141,3 +141,18 @@ def test_toeplitz_gradient_path_against_the_general_path_and_the_oracle(ctx, n, 
             cond = np.linalg.cond(oracle_np.cov(progs[p_], w.t, w.t, True))
             check("toeplitz gradient path: logml vs oracle", on[0][p_], lm, TOL_LOGML, cond)
             check("toeplitz gradient path: gradient vs oracle", on[1][p_], g, 1e-7, cond)
+
+
+def test_toeplitz_gradient_path_on_a_long_series(ctx):
+    """n = 4,200: the weights kernel's LDS image (a and x, 67 KB) needs the opt-in dynamic limit; three
+    stationary trees (never split) against the general path."""
+    w = make_workload("C2", n=4200, P=1, D=1)
+    se = (np.array([3], np.int32), np.array([0.05, 0.9]), 3e-3)
+    per = (np.array([5], np.int32), np.array([0.8, 0.0125, 0.7]), 2e-2)
+    mix = (np.array([4, 5, 6], np.int32), np.array([0.03, 1.3, 0.5, 0.9, 0.0125, 0.4]), 1e-3)
+    progs = [se, per, mix]
+    on, off = _both(ctx, lambda: ctx.logml_grad_batch(progs, w.t, w.y))
+    assert not on[2].any() and not off[2].any()
+    for p_ in range(3):
+        check("toeplitz gradient path: logml vs general path", on[0][p_], off[0][p_], TOL_LOGML, 1e5)
+        check("toeplitz gradient path: gradient vs general path", on[1][p_], off[1][p_], 1e-7, 1e5)
