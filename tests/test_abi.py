@@ -105,6 +105,21 @@ def test_rccl_entry_points_answer_cleanly_without_a_gpu(lib):
         _lib.Comm(_lib.Context(0), b"\0" * 128, 0, 1)
 
 
+def test_round3_entry_points_reject_bad_arguments_without_a_gpu(lib):
+    """The resident gradient job and the storage option: null handles and empty batches are refused
+    with NGP_ERR_ARG before anything touches a device (no compute call is made here)."""
+    import ctypes as C
+    NGP_ERR_ARG = lib.ngp_logml_batch(None, 0, None, 0, None, None, 0, None, None)
+    assert NGP_ERR_ARG != 0
+    h = C.c_void_p()
+    assert lib.ngp_grad_stage(None, 1, None, 10, None, None, 0, C.byref(h)) == NGP_ERR_ARG
+    assert not h.value
+    assert lib.ngp_grad_job_run(None, None, None, None) == NGP_ERR_ARG
+    assert lib.ngp_grad_job_set_params(None, None, None) == NGP_ERR_ARG
+    lib.ngp_grad_job_destroy(None)                         # a null handle is a no-op
+    assert lib.ngp_set_structured_storage(None, 1) == NGP_ERR_ARG
+
+
 def test_context_fails_loudly_without_a_gpu(lib):
     import torch
     if torch.cuda.is_available():
