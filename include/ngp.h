@@ -28,8 +28,10 @@
  *     semantics (k > 0: leading minor k is not positive definite), which the
  *     shim rethrows as PosDefException(k) (src/make_and_fit_model.jl:6-8).
  *   - re-entrant: may be entered concurrently from many host threads
- *     (Threads.@spawn per scenario, src/forecasting.jl:131-132); calls on one
- *     ctx are serialised by a blocking mutex, never a spin.
+ *     (Threads.@spawn per scenario, src/forecasting.jl:131-132); device work of one
+ *     ctx is serialised by a blocking mutex, never a spin, and concurrent one-shot
+ *     calls on the same dates are combined into one launch sequence ("concurrent
+ *     callers" below).
  */
 #ifndef NGP_H
 #define NGP_H
@@ -129,6 +131,27 @@ const char *ngp_strerror(ngp_status st);
 const char *ngp_version(void);
 /* validates a kernel program (arity, stack depth, parameter count) */
 ngp_status  ngp_kernel_check(const ngp_kernel *k);
+
+/* ---- concurrent callers ----------------------------------------------------
+ * The reference enters this boundary from one task per nowcast scenario
+ * (Threads.@spawn, src/forecasting.jl:131-159): D tasks with the P particles of their own clone
+ * each, all on the same dates.  One-shot calls that arrive while the device is busy —
+ * ngp_logml_batch, ngp_predict_batch, ngp_logml_grad_batch, ngp_mixture_sample (S = 1) — are
+ * therefore COMBINED: the calling thread that finds nobody serving takes every pending request,
+ * and requests of the same entry point on bytewise identical dates (same n, same forecast dates
+ * and flags) run as ONE launch sequence of sum(B) items with per-item observation rows; every
+ * caller gets its own results and status.  A call that arrives alone runs exactly as before;
+ * only a caller whose predecessors came in company gives that company at most 200 microseconds to
+ * arrive before it serves (tasks woken together by one sequence come back within microseconds of
+ * each other), and a wait that was in vain is not repeated.  src/forecasting.jl needs no edit to
+ * reach batches of P x (concurrent tasks) items.  A result is the one a single call over the combined
+ * items would give: equal to the caller's own call up to the last bits (batch size decides
+ * launch shapes and therefore summation order, as it always did — see DESIGN.md section 4.14).
+ * ngp_set_combining(ctx, 0) switches it off (every call then waits for ctx's lock and runs alone).
+ * ngp_combine_stats: out4 = { requests seen, launch sequences run for them, largest group,
+ * requests that shared a sequence with at least one other }; reset != 0 clears the counters.  */
+ngp_status ngp_set_combining(ngp_ctx *ctx, int32_t on);
+ngp_status ngp_combine_stats(ngp_ctx *ctx, int64_t *out4, int32_t reset);
 
 /* ---- covariance assembly (diagnostic / small blocks) ---------------------
  * out[b] (n1 x n2, row-major) = k_b(t1_i, t2_j) (+ (noise_b + jitter) on the
@@ -238,7 +261,17 @@ ngp_status ngp_weights_normalize_cols(int32_t P, int32_t D, const double *logw,
  *        passes its rows logw_local [P_local x D] (D scenario columns, row-major); ONE all-gather
  *        of padded shards, then the normalisation of ngp_weights_normalize_cols on every rank:
  *        w_local [P_local x D] (may be NULL), w_all [P_total x D] (may be NULL: what resampling
- *        needs), ess [D], log_norm [D] (may be NULL).  Identical on every rank.                */
+ *        needs), ess [D], log_norm [D] (may be NULL).  Identical on every rank.
+ *        Every rank must own at least one particle: P_total >= world (NGP_ERR_ARG otherwise).
+ *        A non-zero return on ANY rank is fatal for the communicator — the others may be inside
+ *        the all-gather: destroy it and make a new one.  ngp_comm_create gives this process's
+ *        cached device blocks back before its ONE ncclCommInitRank (a collective: never retried
+ *        by one rank alone).
+ *   ngp_weights_unpad_normalize
+ *        the host half of that exchange, for a host that brings its own all-gather: `padded` is
+ *        what gathering equally sized zero-padded shards delivers — world blocks of pmax x D doubles,
+ *        pmax = rows of rank 0 (ngp_shard), block r = rank r's rows, then padding — and comes out
+ *        as w_all [P_total x D] (may be NULL), ess [D] (may be NULL), log_norm [D] (may be NULL).  */
 typedef struct ngp_comm ngp_comm;
 /* the block partition itself (host-only arithmetic): rank's first global particle and its count */
 ngp_status ngp_shard(int32_t P_total, int32_t world, int32_t rank, int32_t *first, int32_t *rows);
@@ -249,6 +282,9 @@ void       ngp_comm_destroy(ngp_comm *comm);
 ngp_status ngp_weights_allgather_normalize(ngp_comm *comm, int32_t P_total, int32_t D,
                                            const double *logw_local, double *w_local,
                                            double *w_all, double *ess, double *log_norm);
+ngp_status ngp_weights_unpad_normalize(int32_t P_total, int32_t world, int32_t D,
+                                       const double *padded, double *w_all, double *ess,
+                                       double *log_norm);
 
 /* ---- staged execution (inputs resident in HBM before the timed region) ----
  * stage  : validate, allocate device buffers, copy inputs host -> device

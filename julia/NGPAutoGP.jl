@@ -105,6 +105,22 @@ function logml_batch(c::Context, progs::Vector{Program}, t::Vector{Float64}, y::
     return out, info
 end
 
+"""
+Concurrent callers (include/ngp.h): one-shot calls entered from several tasks at once — the
+`Threads.@spawn` per scenario of the reference's `forecast_with_nowcasts`, src/forecasting.jl:131-159
+— are combined inside libngp into one launch sequence per group of compatible requests.  On by
+default; `set_combining(ctx, false)` makes every call wait for the context and run alone.
+`combine_stats(ctx)` = (requests, launch sequences, largest group, requests that shared one).
+"""
+set_combining(c::Context, on::Bool) =
+    check(ccall((:ngp_set_combining, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on), "ngp_set_combining")
+function combine_stats(c::Context; reset::Bool = false)
+    out = zeros(Int64, 4)
+    check(ccall((:ngp_combine_stats, LIBNGP), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int32), c.h, out, reset),
+          "ngp_combine_stats")
+    return (requests = out[1], sequences = out[2], largest_group = out[3], shared = out[4])
+end
+
 "storage option of staged value jobs (include/ngp.h): results are bit-identical either way"
 set_structured_storage(c::Context, on::Bool) =
     check(ccall((:ngp_set_structured_storage, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on),
@@ -356,6 +372,21 @@ function weights_allgather_normalize(cm::Comm, logw_local::Matrix{Float64}, P_to
     return permutedims(w_loc), permutedims(w_all), ess, ln
 end
 
+"""
+The host half of that exchange for a host with its own all-gather (MPI.jl, Distributed): `padded` is
+D x pmax x world (column-major; the row-major [world][pmax][D] the C side reads) — every rank's
+zero-padded shard as gathered — and comes out as (w_all P_total x D, ess, log_norm).
+"""
+function weights_unpad_normalize(padded::Array{Float64,3}, P_total::Integer)
+    D, _, world = size(padded)
+    w_all = Matrix{Float64}(undef, D, P_total)
+    ess = Vector{Float64}(undef, D); ln = Vector{Float64}(undef, D)
+    check(ccall((:ngp_weights_unpad_normalize, LIBNGP), Int32,
+                (Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                P_total, world, D, padded, w_all, ess, ln), "ngp_weights_unpad_normalize")
+    return permutedims(w_all), ess, ln
+end
+
 "info[b] > 0  =>  PosDefException(info[b]), as the reference surfaces it (src/make_and_fit_model.jl:6-8)."
 raise_if_not_posdef(info) = (k = findfirst(>(0), info); k === nothing || throw(PosDefException(info[k])))
 
@@ -419,6 +450,10 @@ function transform(z::Float64, kind::Symbol, prior)
 end
 function untransform(th::Float64, kind::Symbol, prior)
     kind === :real && return th
+    # strictly inside the open domain of the kind: a saturated value (gamma == 2.0, unit == 1.0,
+    # a positive parameter == 0) has an infinite latent and would freeze its particle
+    th = kind === :unit ? clamp(th, 1.0e-9, 1.0 - 1.0e-9) :
+         kind === :gamma ? clamp(th, 1.0e-9, 2.0 - 1.0e-9) : max(th, 1.0e-12)
     kind === :unit && return log(th / (1 - th))
     if kind === :gamma
         pr = prior[:gamma]; s = th / 2
@@ -634,20 +669,24 @@ function _hmc_move!(ms::Vector{GPModel}, t, ys, n_leapfrog::Int, eps::Float64)
         end
         return U, dU, lm, progs
     end
-    U0, dU, _, _ = potential(z0)
-    mom = [randn(ms[j].rng, length(z0[i])) for (i, (j, _)) in enumerate(items)]
-    fixed_noise && foreach(p -> (p[end] = 0.0), mom)
-    H0 = [U0[i] + 0.5 * sum(abs2, mom[i]) for i in 1:B]
-    z = deepcopy(z0)
-    pm = [mom[i] .- 0.5 * eps .* dU[i] for i in 1:B]
-    U1 = U0; lm1 = zeros(B); progs1 = parts
-    for step in 1:n_leapfrog
-        z = [z[i] .+ eps .* pm[i] for i in 1:B]
-        U1, dU, lm1, progs1 = potential(z)
-        h = step < n_leapfrog ? eps : 0.5 * eps
-        pm = [pm[i] .- h .* dU[i] for i in 1:B]
+    local H0, U1, lm1, progs1, pm
+    try
+        U0, dU, _, _ = potential(z0)
+        mom = [randn(ms[j].rng, length(z0[i])) for (i, (j, _)) in enumerate(items)]
+        fixed_noise && foreach(p -> (p[end] = 0.0), mom)
+        H0 = [U0[i] + 0.5 * sum(abs2, mom[i]) for i in 1:B]
+        z = deepcopy(z0)
+        pm = [mom[i] .- 0.5 * eps .* dU[i] for i in 1:B]
+        U1 = U0; lm1 = zeros(B); progs1 = parts
+        for step in 1:n_leapfrog
+            z = [z[i] .+ eps .* pm[i] for i in 1:B]
+            U1, dU, lm1, progs1 = potential(z)
+            h = step < n_leapfrog ? eps : 0.5 * eps
+            pm = [pm[i] .- h .* dU[i] for i in 1:B]
+        end
+    finally
+        job === nothing || close(job)     # the device arena goes back whatever a step threw
     end
-    job === nothing || close(job)
     acc = 0
     for (i, (j, k)) in enumerate(items)
         H1 = U1[i] + 0.5 * sum(abs2, pm[i])

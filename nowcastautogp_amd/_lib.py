@@ -34,7 +34,8 @@ SYMBOLS = (
     "ngp_job_mixed_stats", "ngp_job_destroy", "ngp_factor_create", "ngp_factor_logml", "ngp_factor_nowcast",
     "ngp_factor_destroy", "ngp_mixture_sample", "ngp_set_structured_storage", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
     "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
-    "ngp_selftest_mfma_f32_layout",
+    "ngp_selftest_mfma_f32_layout", "ngp_set_combining", "ngp_combine_stats",
+    "ngp_weights_unpad_normalize",
 )
 
 
@@ -97,6 +98,7 @@ def load():
         "ngp_comm_create": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
         "ngp_comm_destroy": (None, [vp]),
         "ngp_weights_allgather_normalize": (i32, [vp, i32, i32, f64p, f64p, f64p, f64p, f64p]),
+        "ngp_weights_unpad_normalize": (i32, [i32, i32, i32, f64p, f64p, f64p, f64p]),
         "ngp_logml_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, C.POINTER(vp)]),
         "ngp_predict_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, i32, f64p, i32,
                                     C.POINTER(vp)]),
@@ -114,6 +116,8 @@ def load():
         "ngp_mixture_sample": (i32, [vp, i32, i32, i32, f64p, f64p, f64p, i32, C.c_uint64, f64p,
                                      i32p, i32p]),
         "ngp_set_structured_storage": (i32, [vp, i32]),
+        "ngp_set_combining": (i32, [vp, i32]),
+        "ngp_combine_stats": (i32, [vp, C.POINTER(C.c_int64), i32]),
         "ngp_profile_enable": (i32, [vp, i32]),
         "ngp_profile_reset": (i32, [vp]),
         "ngp_profile_get": (i32, [vp, C.POINTER(NgpProfile)]),
@@ -170,6 +174,18 @@ def weights_normalize_cols(logw):
 
 
 NGP_ERR_UNAVAILABLE = -6
+
+
+def weights_unpad_normalize(padded, P_total: int, world: int):
+    """``ngp_weights_unpad_normalize``: ``padded`` [world, pmax, D] (what an all-gather of
+    zero-padded shards delivers) -> (w_all [P_total, D], ess [D], log_norm [D])."""
+    padded = as_f64(padded)
+    D = padded.shape[-1]
+    w = np.empty((int(P_total), D))
+    ess, ln = np.empty(D), np.empty(D)
+    _chk(load().ngp_weights_unpad_normalize(int(P_total), int(world), D, dptr(padded), dptr(w),
+                                            dptr(ess), dptr(ln)), "ngp_weights_unpad_normalize")
+    return w, ess, ln
 
 
 def shard(P_total: int, world: int, rank: int):
@@ -555,6 +571,17 @@ class Context:
         return Job(self, h, ka.n, D, m, (ka, t, y, t_add, y_add, t_new))
 
     # ---- measurement ----------------------------------------------------------------------
+    def set_combining(self, on=True):
+        """Combining of concurrent one-shot callers (include/ngp.h "concurrent callers"); on by
+        default."""
+        _chk(load().ngp_set_combining(self._h, 1 if on else 0), "ngp_set_combining")
+
+    def combine_stats(self, reset=False) -> dict:
+        out = (C.c_int64 * 4)()
+        _chk(load().ngp_combine_stats(self._h, out, 1 if reset else 0), "ngp_combine_stats")
+        return dict(requests=int(out[0]), sequences=int(out[1]), largest_group=int(out[2]),
+                    shared=int(out[3]))
+
     def set_structured_storage(self, on=True):
         """Storage option of staged value jobs (include/ngp.h): results are bit-identical either way."""
         _chk(load().ngp_set_structured_storage(self._h, int(bool(on))), "ngp_set_structured_storage")

@@ -284,6 +284,10 @@ class GPModel:
     def _eng(self):
         if self.engine is None:
             self.engine = default_engine()
+        if self.__dict__.get("_spec_checked") is False:   # loaded from a dict before it had an engine
+            from . import wire
+            self._spec_checked = True
+            wire.check_spec(self.engine, self.__dict__.get("wire_spec"))
         return self.engine
 
     # -- data views -----------------------------------------------------------------------------
@@ -367,7 +371,7 @@ class GPModel:
         m.n_obs = self.n_obs
         m._perm = self._perm.copy()
         m._logml = self._logml.copy()
-        if hasattr(self, "wire_spec"):
+        if self.__dict__.get("wire_spec") is not None:
             m.wire_spec = dict(self.wire_spec)
         if root is None:
             m.rng_shared = copy.deepcopy(self.rng_shared)
@@ -620,6 +624,7 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
             th[i_gamma] = np.clip(th[i_gamma], 1e-9, 2.0 - 1e-9)
         if i_unit.size:
             th[i_unit] = np.clip(th[i_unit], 1e-9, 1.0 - 1e-9)
+        # (the same margins as gp.clip_flat, which the accepted parameters go through)
         if ka is not None:      # same structures, new parameters: refill the C array in place
             ka.set_params(th[i_param], th[last])
             lm, g, info = job.run(ka) if job is not None else eng.logml_grad_flat(ka, t, Y)
@@ -635,23 +640,28 @@ def _hmc_move(models: Sequence[GPModel], t, ys, n_leapfrog: int, eps: float, Y=N
             dU[last] = 0.0
         return U, dU, lm
 
-    U0, dU, _ = potential(z0)
-    mom = np.concatenate([prng[i].standard_normal(int(sizes[i])) for i in range(B)])
-    if fixed_noise:
-        mom[last] = 0.0
-    H0 = U0 + 0.5 * sums(mom * mom)
-    z = z0.copy()
-    pm = mom - 0.5 * eps * dU
-    lm1 = U1 = None
-    for step in range(n_leapfrog):
-        z = z + eps * pm
-        U1, dU, lm1 = potential(z)
-        pm = pm - (eps if step < n_leapfrog - 1 else 0.5 * eps) * dU
-    if job is not None:
-        job.close()
+    try:
+        U0, dU, _ = potential(z0)
+        mom = np.concatenate([prng[i].standard_normal(int(sizes[i])) for i in range(B)])
+        if fixed_noise:
+            mom[last] = 0.0
+        H0 = U0 + 0.5 * sums(mom * mom)
+        z = z0.copy()
+        pm = mom - 0.5 * eps * dU
+        lm1 = U1 = None
+        for step in range(n_leapfrog):
+            z = z + eps * pm
+            U1, dU, lm1 = potential(z)
+            pm = pm - (eps if step < n_leapfrog - 1 else 0.5 * eps) * dU
+    finally:
+        if job is not None:   # the device arena goes back whatever a step raised
+            job.close()
     with np.errstate(invalid="ignore", over="ignore"):
         H1 = U1 + 0.5 * sums(pm * pm)
-    th_new, _ = to_theta(z)
+    # what is installed on acceptance is what the last evaluation saw: clipped into the open domain
+    # of every kind, so no particle ever carries a saturated parameter (an infinite latent)
+    zc = z if np.isfinite(z).all() else np.nan_to_num(z, nan=0.0, posinf=50.0, neginf=-50.0)
+    th_new = gp.clip_flat(np.clip(to_theta(zc)[0], -1e6, 1e6), codes)
     acc = 0
     for i, (j, k) in enumerate(items):
         u = prng[i].random()      # drawn for every particle: the stream does not depend on H
@@ -677,13 +687,19 @@ def mcmc_structure(model: GPModel, n_mcmc: int, n_hmc: int, hmc_config: Optional
 
 
 def mcmc_parameters_lockstep(models: Sequence[GPModel], n_hmc: int,
-                             hmc_config: Optional[dict] = None) -> None:
-    """``mcmc_parameters!`` (reference src/forecasting.jl:65,148) for D models at once."""
+                             hmc_config: Optional[dict] = None, _obs=None):
+    """``mcmc_parameters!`` (reference src/forecasting.jl:65,148) for D models at once.
+    ``_obs``: the ``(t, ys, Y)`` a previous call on the same models and data returned — the
+    per-draw refinement of ``forecast`` (src/forecasting.jl:63-68) then builds the P x D
+    observation rows (210 MB at 64 x 200 items of 2,049 points) once, not once per draw."""
     cfgd = {**DEFAULT_HMC, **(hmc_config or {})}
-    t, ys = _group_obs(models)
-    Y = _all_items_y(models, ys)
+    if _obs is None:
+        t, ys = _group_obs(models)
+        _obs = (t, ys, _all_items_y(models, ys))
+    t, ys, Y = _obs
     for _ in range(int(n_hmc)):
         _hmc_move(models, t, ys, cfgd["n_leapfrog"], cfgd["eps"], Y)
+    return _obs
 
 
 def mcmc_structure_lockstep(models: Sequence[GPModel], n_mcmc: int, n_hmc: int,
@@ -911,7 +927,11 @@ def predict_mvn_lockstep(models: Sequence[GPModel], ds, noise_on_new: bool = Tru
     t, ys = _group_obs(models)
     t_new = models[0].ds_transform.apply(to_days(list(ds)))
     eng = models[0]._eng()
-    fac = models[0]._factor() if D == 1 else None
+    # (a scenario clone that forecasts once asks the one-shot entry point — concurrent tasks'
+    # calls are combined there, include/ngp.h "concurrent callers" — instead of building a
+    # resident factor for a single query)
+    fac = (models[0]._factor()
+           if D == 1 and not models[0].__dict__.get("_one_shot_predict", False) else None)
     if D > 1:
         progs = [p for m in models for p in m.programs()]
         Y = _item_y(ys, [j for j, m in enumerate(models) for _ in m.particles])

@@ -1,6 +1,8 @@
 // ngp_api.hip — host side of libngp: contexts, staged jobs, launch schedule, C-ABI (include/ngp.h).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
@@ -249,6 +251,8 @@ bool detect_lattice(const std::vector<double> &t, double *h_out, std::vector<int
 // ---------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------
+struct ngp_comb_req;   // one caller's request while it waits to be combined (ngp_combine below)
+
 struct ngp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -282,6 +286,18 @@ struct ngp_ctx {
     }
     ngp_spec spec{};
     std::mutex mu;
+    // Flat combining of concurrent callers ("combining" section below): one-shot calls that arrive
+    // while the device is busy wait in `pending`; the thread that finds nobody serving takes ALL of
+    // them and runs every group of compatible requests as ONE launch sequence.  qmu guards these
+    // fields only and is never held across a device call; mu stays the execution lock.
+    std::mutex qmu;
+    std::vector<ngp_comb_req *> pending;
+    bool combining = false, combine_on = true;
+    int64_t comb_stats[4] = {};   // requests | launch sequences | largest group | requests that shared one
+    // company seen lately: the number of requests the last server took (decays when a wait for
+    // it was in vain) and the condition a would-be server waits on for at most COMB_LINGER_US
+    size_t comb_expect = 1;
+    std::condition_variable comb_arrival;
     bool profiling = false;
     bool toeplitz = true;   // ngp_set_structured_storage
     ngp_profile prof{};
@@ -841,15 +857,18 @@ template <class T> ngp_status job_alloc(ngp_job *j, T **p, size_t count) {
 
 // Stage a job in its general form: P kernels; base data (t[n], y [P or 1][n]); d appended
 // times; D scenarios y_add [(P or 1)][D][d]; m forecast times.
+// yrows (combined calls, ngp_combine below): item b's observations are yrows[b][0..n) — the rows of
+// several callers' arrays, never copied into one matrix on the host; y / ldy are then not read.
 ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, const double *t,
                          const double *y, int64_t ldy, int d, const double *t_add, int D,
                          const double *y_add, int64_t ld_yadd_item, int m, const double *t_new,
-                         int noise_on_new, ngp_job **out) {
+                         int noise_on_new, ngp_job **out, const double *const *yrows = nullptr) {
     if (!c || !out || !kernels || P <= 0 || n < 0 || d < 0 || m < 0 || D <= 0) return NGP_ERR_ARG;
     if (n + d <= 0) return NGP_ERR_ARG;
-    if ((n > 0 && (!t || !y)) || (d > 0 && (!t_add || !y_add)) || (m > 0 && !t_new))
+    if ((n > 0 && (!t || (!y && !yrows))) || (d > 0 && (!t_add || !y_add)) || (m > 0 && !t_new))
         return NGP_ERR_ARG;
     *out = nullptr;
+    auto yrow = [&](int b) { return yrows ? yrows[b] : y + (int64_t)b * ldy; };
     std::vector<DevProgram> hp((size_t)P);
     int maxstat = 0, maxcp = 0;
     for (int i = 0; i < P; ++i) {
@@ -872,7 +891,7 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     g.naux_pad = (g.naux + NB - 1) / NB * NB;
     g.D = D;
     g.noise_on_new = noise_on_new ? 1 : 0;
-    g.y_shared = (ldy == 0) ? 1 : 0;
+    g.y_shared = (ldy == 0 && !yrows) ? 1 : 0;
     g.ld = g.n0;
     g.item_stride = (int64_t)(g.n0 + g.naux_pad) * g.n0;
     if (item_too_large(g.item_stride)) return NGP_ERR_TOO_LARGE;
@@ -966,11 +985,11 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
         for (int a = 0; a < d; ++a) h_taux[g.tail + a] = t_add[a];
         for (int i = 0; i < m; ++i) h_taux[g.da + i] = t_new[i];
         for (int b = 0; b < ny; ++b)
-            for (int i = 0; i < g.n0; ++i) h_y0[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
+            if (g.n0 > 0) std::memcpy(h_y0 + (size_t)b * g.n0, yrow(b), 8 * (size_t)g.n0);
         for (int b = 0; b < ny; ++b)
             for (int sc = 0; sc < D; ++sc) {
                 double *dst = h_ya + ((size_t)b * D + sc) * g.da;
-                for (int a = 0; a < g.tail; ++a) dst[a] = y[(int64_t)b * ldy + g.n0 + a];
+                for (int a = 0; a < g.tail; ++a) dst[a] = yrow(b)[g.n0 + a];
                 for (int a = 0; a < d; ++a)
                     dst[g.tail + a] = y_add[(int64_t)b * ld_yadd_item + (int64_t)sc * d + a];
             }
@@ -1420,24 +1439,27 @@ static ngp_status run_fetch_destroy(ngp_job *job, double *lb, double *lf, double
     return st;
 }
 
-extern "C" ngp_status ngp_logml_batch(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
-                                      const double *t, const double *y, int64_t ldy, double *logml,
-                                      int32_t *info) {
+static ngp_status logml_direct(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
+                               const double *t, const double *y, int64_t ldy, double *logml,
+                               int32_t *info) {
     ngp_job *job = nullptr;
     ngp_status st = ngp_logml_stage(c, B, k, n, t, y, ldy, &job);
     if (st) return st;
     return run_fetch_destroy(job, nullptr, logml, nullptr, nullptr, info);
 }
 
-extern "C" ngp_status ngp_predict_batch(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
-                                        const double *t, const double *y, int64_t ldy, int32_t m,
-                                        const double *t_new, int32_t noise_on_new, double *mu,
-                                        double *sigma, double *logml, int32_t *info) {
+static ngp_status predict_direct(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
+                                 const double *t, const double *y, int64_t ldy, int32_t m,
+                                 const double *t_new, int32_t noise_on_new, double *mu,
+                                 double *sigma, double *logml, int32_t *info) {
     ngp_job *job = nullptr;
     ngp_status st = ngp_predict_stage(c, B, k, n, t, y, ldy, m, t_new, noise_on_new, &job);
     if (st) return st;
     return run_fetch_destroy(job, nullptr, logml, mu, sigma, info);
 }
+
+// (ngp_logml_batch, ngp_predict_batch, ngp_logml_grad_batch and ngp_mixture_sample are defined in
+// the "combining" section further down: they enter through combine_submit)
 
 extern "C" ngp_status ngp_nowcast_batch(ngp_ctx *c, int32_t P, const ngp_kernel *k, int32_t n,
                                         const double *t, const double *y, int32_t d,
@@ -1755,10 +1777,12 @@ namespace {
 
 // toep_path: the items are stationary trees on a regular series — aux rows [y' ; e_1'] instead of
 // [I ; y'] (the caller, ngp_grad_stage, has checked both)
+// yrows: item b's observations are yrows[b][0..n) (y / ldy are then not read) — a subset of a
+// caller's batch, or the rows of several callers' arrays in a combined call
 ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
                            const double *t, const double *y, int64_t ldy, bool toep_path,
-                           GradLeaf **out) {
-    if (!c || !out || !kernels || !t || !y || B <= 0 || n <= 0) return NGP_ERR_ARG;
+                           GradLeaf **out, const double *const *yrows = nullptr) {
+    if (!c || !out || !kernels || !t || (!y && !yrows) || B <= 0 || n <= 0) return NGP_ERR_ARG;
     *out = nullptr;
     GradLeaf *j = new (std::nothrow) GradLeaf();
     if (!j) return NGP_ERR_TOO_LARGE;
@@ -1795,7 +1819,7 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
     g.naux = toep_path ? 2 : g.n0 + 1;
     g.naux_pad = toep_path ? NB : g.n0 + NB;
     g.D = 1;
-    g.y_shared = (ldy == 0) ? 1 : 0;
+    g.y_shared = (ldy == 0 && !yrows) ? 1 : 0;
     g.ld = g.n0;
     g.item_stride = (int64_t)(g.n0 + g.naux_pad) * g.n0;
     if (item_too_large(g.item_stride)) return NGP_ERR_TOO_LARGE;
@@ -1832,7 +1856,7 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
         double *ht = (double *)(j->h_in.data() + j->o_t), *hy = (double *)(j->h_in.data() + j->o_y);
         for (int i = 0; i < g.n0; ++i) ht[i] = t[std::min(i, n - 1)];
         for (int b = 0; b < ny; ++b)
-            for (int i = 0; i < n; ++i) hy[(size_t)b * g.n0 + i] = y[(int64_t)b * ldy + i];
+            std::memcpy(hy + (size_t)b * g.n0, yrows ? yrows[b] : y + (int64_t)b * ldy, 8 * (size_t)n);
         if (g.lattice) std::memcpy(j->h_in.data() + j->o_q, h_q.data(), 4 * (size_t)g.n0);
     }
     std::lock_guard<std::mutex> lk(c->mu);
@@ -2164,12 +2188,26 @@ struct ngp_grad_job {
     std::vector<double> buf_p, buf_n, buf_lm, buf_g, buf_lm2, buf_g2;
     std::vector<int32_t> buf_info, buf_info2;
     bool side_by_side = false;                  // a small split batch: both leaves in flight together
+    // Small jobs keep a host copy of what a ONE-SHOT call over their items would take (trees and
+    // current parameters in the caller's order, dates, observation rows): when several tasks run
+    // their jobs at the same moment — the leapfrog steps of the per-scenario HMC moves of
+    // forecast_with_nowcasts, src/forecasting.jl:145-148 — the runs are combined into one call
+    // over all their items ("combining" section); alone, a run uses the resident inputs as before.
+    std::vector<int32_t> h_ops;
+    std::vector<double> h_params, h_t, h_y;
+    std::vector<ngp_kernel> h_k;
+    int32_t n = 0;
+    int64_t h_ldy = 0;
 };
+// host copies up to this size (64 particles x 2,049 points = 1 MB; a lockstep job of 12,800 items
+// is 210 MB and has no use for company)
+static constexpr size_t GRAD_JOB_HOST_COPY_BYTES = (size_t)16 << 20;
 
-extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
-                                     const double *t, const double *y, int64_t ldy,
-                                     ngp_grad_job **out) {
-    if (!c || !out || !kernels || !t || !y || B <= 0 || n <= 0) return NGP_ERR_ARG;
+static ngp_status grad_stage_impl(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
+                                  const double *t, const double *y, int64_t ldy,
+                                  const double *const *yrows, ngp_grad_job **out,
+                                  bool keep_host = false) {
+    if (!c || !out || !kernels || !t || (!y && !yrows) || B <= 0 || n <= 0) return NGP_ERR_ARG;
     *out = nullptr;
     for (int i = 0; i < B; ++i) {
         ngp_status st = check_program(&kernels[i]);
@@ -2237,14 +2275,16 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
     auto stage_leaf = [&](const std::vector<int32_t> &idx, bool toep_path, GradLeaf **leaf) -> ngp_status {
         if (idx.empty()) return NGP_OK;
         if ((int)idx.size() == B)   // the whole batch: the caller's arrays as they are
-            return grad_leaf_stage(c, B, kernels, n, t, y, ldy, toep_path, leaf);
+            return grad_leaf_stage(c, B, kernels, n, t, y, ldy, toep_path, leaf, yrows);
         std::vector<ngp_kernel> ks(idx.size());
         for (size_t a = 0; a < idx.size(); ++a) ks[a] = kernels[idx[a]];
-        if (ldy == 0) return grad_leaf_stage(c, (int32_t)idx.size(), ks.data(), n, t, y, 0, toep_path, leaf);
-        std::vector<double> ys(idx.size() * (size_t)n);
+        if (!yrows && ldy == 0)
+            return grad_leaf_stage(c, (int32_t)idx.size(), ks.data(), n, t, y, 0, toep_path, leaf);
+        std::vector<const double *> rows(idx.size());   // the leaf's rows where they lie
         for (size_t a = 0; a < idx.size(); ++a)
-            std::memcpy(ys.data() + a * (size_t)n, y + (int64_t)idx[a] * ldy, 8 * (size_t)n);
-        return grad_leaf_stage(c, (int32_t)idx.size(), ks.data(), n, t, ys.data(), n, toep_path, leaf);
+            rows[a] = yrows ? yrows[idx[a]] : y + (int64_t)idx[a] * ldy;
+        return grad_leaf_stage(c, (int32_t)idx.size(), ks.data(), n, t, nullptr, 0, toep_path, leaf,
+                               rows.data());
     };
     ngp_status st = stage_leaf(j->idx_gen, false, &j->gen);
     if (!st) st = stage_leaf(j->idx_toep, true, &j->toep);
@@ -2253,8 +2293,41 @@ extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *ke
         grad_leaf_destroy(j->toep);
         return st;
     }
+    j->n = n;
+    const bool shared = !yrows && ldy == 0;
+    if (keep_host && (size_t)(shared ? 1 : B) * (size_t)n * 8 <= GRAD_JOB_HOST_COPY_BYTES) {
+        j->h_t.assign(t, t + n);
+        j->h_ldy = shared ? 0 : n;
+        j->h_y.resize((size_t)(shared ? 1 : B) * (size_t)n);
+        for (int b = 0; b < (shared ? 1 : B); ++b)
+            std::memcpy(j->h_y.data() + (size_t)b * n, yrows ? yrows[b] : y + (int64_t)b * ldy, 8 * (size_t)n);
+        size_t nops = 0;
+        for (int i = 0; i < B; ++i) nops += (size_t)kernels[i].n_ops;
+        j->h_ops.reserve(nops);
+        j->h_params.resize(std::max<size_t>(j->poff[(size_t)B], 1));
+        j->h_k.resize((size_t)B);
+        for (int i = 0; i < B; ++i) {
+            j->h_ops.insert(j->h_ops.end(), kernels[i].ops, kernels[i].ops + kernels[i].n_ops);
+            if (kernels[i].n_params > 0)
+                std::memcpy(j->h_params.data() + j->poff[(size_t)i], kernels[i].params,
+                            8 * (size_t)kernels[i].n_params);
+        }
+        size_t o = 0;
+        for (int i = 0; i < B; ++i) {
+            j->h_k[(size_t)i] = ngp_kernel{kernels[i].n_ops, kernels[i].n_params, j->h_ops.data() + o,
+                                           j->h_params.data() + j->poff[(size_t)i], kernels[i].noise};
+            o += (size_t)kernels[i].n_ops;
+        }
+    }
     *out = j.release();
     return NGP_OK;
+}
+
+extern "C" ngp_status ngp_grad_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
+                                     const double *t, const double *y, int64_t ldy,
+                                     ngp_grad_job **out) {
+    if (!y) return NGP_ERR_ARG;
+    return grad_stage_impl(c, B, kernels, n, t, y, ldy, nullptr, out, true);
 }
 
 extern "C" ngp_status ngp_grad_job_set_params(ngp_grad_job *j, const double *params,
@@ -2274,10 +2347,16 @@ extern "C" ngp_status ngp_grad_job_set_params(ngp_grad_job *j, const double *par
     };
     ngp_status st = set_leaf(j->gen, j->idx_gen);
     if (!st) st = set_leaf(j->toep, j->idx_toep);
+    if (!st && !j->h_k.empty()) {   // the one-shot form of the job follows
+        if (j->poff[(size_t)j->B] > 0) std::memcpy(j->h_params.data(), params, 8 * j->poff[(size_t)j->B]);
+        for (int i = 0; i < j->B; ++i) j->h_k[(size_t)i].noise = noise[i];
+    }
     return st;
 }
 
-extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *grad, int32_t *info) {
+// the run on the job's resident inputs (ngp_grad_job_run, defined in the "combining" section, comes
+// here when the job is alone)
+static ngp_status grad_job_run_resident(ngp_grad_job *j, double *logml, double *grad, int32_t *info) {
     if (!j || !grad) return NGP_ERR_ARG;
     auto scatter = [&](const std::vector<int32_t> &idx, const std::vector<double> &lm,
                        const std::vector<double> &g, const std::vector<int32_t> &inf) {
@@ -2343,15 +2422,15 @@ extern "C" void ngp_grad_job_destroy(ngp_grad_job *j) {
     delete j;
 }
 
-extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kernel *kernels,
-                                           int32_t n, const double *t, const double *y,
-                                           int64_t ldy, double *logml, double *grad,
-                                           int32_t *info) {
+static ngp_status logml_grad_direct(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int32_t n,
+                                    const double *t, const double *y, int64_t ldy,
+                                    const double *const *yrows, double *logml, double *grad,
+                                    int32_t *info) {
     if (!grad) return NGP_ERR_ARG;
     ngp_grad_job *j = nullptr;
-    ngp_status st = ngp_grad_stage(c, B, kernels, n, t, y, ldy, &j);
+    ngp_status st = grad_stage_impl(c, B, kernels, n, t, y, ldy, yrows, &j);
     if (st) return st;
-    st = ngp_grad_job_run(j, logml, grad, info);
+    st = grad_job_run_resident(j, logml, grad, info);
     ngp_grad_job_destroy(j);
     return st;
 }
@@ -2449,13 +2528,6 @@ static ngp_status mixture_sample_impl(ngp_ctx *c, int32_t P, int32_t S, int32_t 
     return e == hipSuccess ? NGP_OK : (ngp_status)e;
 }
 
-extern "C" ngp_status ngp_mixture_sample(ngp_ctx *c, int32_t P, int32_t S, int32_t m,
-                                         const double *w, const double *mu, const double *sigma,
-                                         int32_t draws, uint64_t seed, double *out, int32_t *comp,
-                                         int32_t *info) {
-    return mixture_sample_impl(c, P, S, m, w, mu, sigma, draws, seed, nullptr, out, comp, info);
-}
-
 extern "C" ngp_status ngp_mixture_sample_indep(ngp_ctx *c, int32_t P, int32_t S, int32_t m,
                                                const double *w, const double *mu,
                                                const double *sigma, int32_t draws,
@@ -2463,6 +2535,366 @@ extern "C" ngp_status ngp_mixture_sample_indep(ngp_ctx *c, int32_t P, int32_t S,
                                                int32_t *info) {
     if (!seeds) return NGP_ERR_ARG;
     return mixture_sample_impl(c, P, S, m, w, mu, sigma, draws, 0, seeds, out, comp, info);
+}
+
+// ---------------------------------------------------------------------------------------
+// Combining concurrent callers (flat combining)
+//
+// The reference enters the boundary from one task per nowcast scenario (Threads.@spawn,
+// src/forecasting.jl:131-159): D tasks, each with the P particles of its own clone, all on the same
+// dates.  Serialised on the context they are D calls of P items — the small-batch regime D times
+// over.  Here a one-shot call (ngp_logml_batch, ngp_predict_batch, ngp_logml_grad_batch,
+// ngp_mixture_sample with S = 1) is a REQUEST: it joins `pending`; whoever finds nobody serving takes
+// everything that is pending, sorts it into groups of compatible requests — same entry point, same
+// series length, bytewise identical dates (a hash, then memcmp), same forecast dates / flags — and
+// runs every group as ONE launch sequence over the concatenated items with per-item observation
+// rows (the `ldy = n` form every entry point already has; a group of one takes the unchanged
+// one-shot path), scatters the results and wakes the callers.  No timer and no extra thread:
+// requests pile up by themselves while the device is busy with the previous sequence.  A server
+// that has finished its own request hands the role to the first waiter, so nobody serves forever.
+// Requests that are not compatible run in arrival order, as before; staged jobs, resident factors
+// and the collective do not combine (they take ctx->mu as they always did).
+// A merged group that fails as a whole (device memory, a HIP error) is re-run request by request,
+// so every caller gets the status its own call would have had.
+// ---------------------------------------------------------------------------------------
+enum { CK_LOGML = 0, CK_PREDICT = 1, CK_GRAD = 2, CK_MIXTURE = 3 };
+struct ngp_comb_req {
+    int kind = CK_LOGML;
+    // CK_LOGML / CK_PREDICT / CK_GRAD
+    int32_t B = 0, n = 0, m = 0, noise_on_new = 0;
+    const ngp_kernel *k = nullptr;
+    const double *t = nullptr, *y = nullptr, *t_new = nullptr;
+    int64_t ldy = 0;
+    double *logml = nullptr, *grad = nullptr, *mu = nullptr, *sigma = nullptr;
+    int32_t *info = nullptr;
+    ngp_grad_job *gj = nullptr;   // CK_GRAD from ngp_grad_job_run: alone it runs on its resident inputs
+    // CK_MIXTURE (one mixture of P components: ngp_mixture_sample with S = 1)
+    int32_t P = 0, draws = 0;
+    const double *w = nullptr, *cmu = nullptr, *csigma = nullptr;
+    uint64_t seed = 0;
+    double *out = nullptr;
+    int32_t *comp = nullptr;
+    // what must be equal for two requests to share a launch sequence, hashed by the caller
+    uint64_t key = 0;
+    ngp_status st = NGP_OK;
+    bool done = false;
+    std::condition_variable cv;
+};
+
+namespace {
+
+inline uint64_t fnv_words(uint64_t h, const void *p, size_t bytes) {
+    const unsigned char *b = (const unsigned char *)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, b + i, 8);
+        h = (h ^ w) * 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    for (; i < bytes; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h;
+}
+
+uint64_t comb_key(const ngp_comb_req &r) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    const int32_t head[6] = {r.kind, r.n, r.m, r.noise_on_new, r.P, r.draws};
+    h = fnv_words(h, head, sizeof(head));
+    if (r.kind != CK_MIXTURE) {
+        h = fnv_words(h, r.t, 8 * (size_t)r.n);
+        if (r.m > 0) h = fnv_words(h, r.t_new, 8 * (size_t)r.m);
+    }
+    return h;
+}
+
+bool comb_same(const ngp_comb_req &a, const ngp_comb_req &b) {
+    if (a.kind != b.kind || a.key != b.key || a.n != b.n || a.m != b.m ||
+        a.noise_on_new != b.noise_on_new || a.P != b.P || a.draws != b.draws)
+        return false;
+    if (a.kind == CK_MIXTURE) return true;
+    if (std::memcmp(a.t, b.t, 8 * (size_t)a.n) != 0) return false;
+    return a.m == 0 || std::memcmp(a.t_new, b.t_new, 8 * (size_t)a.m) == 0;
+}
+
+// the request alone: the one-shot path as it always was
+ngp_status comb_run_one(ngp_ctx *c, ngp_comb_req &r) {
+    switch (r.kind) {
+    case CK_LOGML: return logml_direct(c, r.B, r.k, r.n, r.t, r.y, r.ldy, r.logml, r.info);
+    case CK_PREDICT:
+        return predict_direct(c, r.B, r.k, r.n, r.t, r.y, r.ldy, r.m, r.t_new, r.noise_on_new, r.mu,
+                              r.sigma, r.logml, r.info);
+    case CK_GRAD:
+        if (r.gj) return grad_job_run_resident(r.gj, r.logml, r.grad, r.info);
+        return logml_grad_direct(c, r.B, r.k, r.n, r.t, r.y, r.ldy, nullptr, r.logml, r.grad, r.info);
+    default:
+        return mixture_sample_impl(c, r.P, 1, r.m, r.w, r.cmu, r.csigma, r.draws, r.seed, nullptr,
+                                   r.out, r.comp, r.info);
+    }
+}
+
+// a group of compatible requests as ONE call; the results go back to every request's own arrays
+ngp_status comb_run_group(ngp_ctx *c, const std::vector<ngp_comb_req *> &grp) {
+    const ngp_comb_req &r0 = *grp[0];
+    if (r0.kind == CK_MIXTURE) {
+        // K mixtures of P components each = ngp_mixture_sample_indep with one seed per request
+        const size_t K = grp.size(), P = (size_t)r0.P, m = (size_t)r0.m, dr = (size_t)r0.draws;
+        std::vector<double> w(K * P), mu(K * P * m), sg(K * P * m * m), out(K * dr * m);
+        std::vector<uint64_t> seeds(K);
+        std::vector<int32_t> comp(K * dr), info(K * P);
+        for (size_t a = 0; a < K; ++a) {
+            std::memcpy(w.data() + a * P, grp[a]->w, 8 * P);
+            std::memcpy(mu.data() + a * P * m, grp[a]->cmu, 8 * P * m);
+            std::memcpy(sg.data() + a * P * m * m, grp[a]->csigma, 8 * P * m * m);
+            seeds[a] = grp[a]->seed;
+        }
+        const ngp_status st = mixture_sample_impl(c, r0.P, (int32_t)K, r0.m, w.data(), mu.data(), sg.data(),
+                                                  r0.draws, 0, seeds.data(), out.data(), comp.data(),
+                                                  info.data());
+        if (st) return st;
+        for (size_t a = 0; a < K; ++a) {
+            std::memcpy(grp[a]->out, out.data() + a * dr * m, 8 * dr * m);
+            if (grp[a]->comp) std::memcpy(grp[a]->comp, comp.data() + a * dr, 4 * dr);
+            if (grp[a]->info) std::memcpy(grp[a]->info, info.data() + a * P, 4 * P);
+        }
+        return NGP_OK;
+    }
+    size_t Bt = 0;
+    for (const ngp_comb_req *r : grp) Bt += (size_t)r->B;
+    if (Bt > (size_t)0x7fffffff) return NGP_ERR_TOO_LARGE;
+    std::vector<ngp_kernel> ks;
+    std::vector<const double *> rows;
+    ks.reserve(Bt);
+    rows.reserve(Bt);
+    for (const ngp_comb_req *r : grp)
+        for (int b = 0; b < r->B; ++b) {
+            ks.push_back(r->k[b]);
+            rows.push_back(r->y + (int64_t)b * r->ldy);
+        }
+    std::vector<double> lm(Bt);
+    std::vector<int32_t> info(Bt);
+    if (r0.kind == CK_GRAD) {
+        size_t ng = 0;
+        for (const ngp_kernel &k : ks) ng += (size_t)k.n_params + 1;
+        std::vector<double> grad(ng);
+        const ngp_status st = logml_grad_direct(c, (int32_t)Bt, ks.data(), r0.n, r0.t, nullptr, 0,
+                                                rows.data(), lm.data(), grad.data(), info.data());
+        if (st) return st;
+        size_t b0 = 0, g0 = 0;
+        for (ngp_comb_req *r : grp) {
+            size_t len = 0;
+            for (int b = 0; b < r->B; ++b) len += (size_t)r->k[b].n_params + 1;
+            std::memcpy(r->grad, grad.data() + g0, 8 * len);
+            if (r->logml) std::memcpy(r->logml, lm.data() + b0, 8 * (size_t)r->B);
+            if (r->info) std::memcpy(r->info, info.data() + b0, 4 * (size_t)r->B);
+            b0 += (size_t)r->B;
+            g0 += len;
+        }
+        return NGP_OK;
+    }
+    const size_t m = (size_t)r0.m;
+    std::vector<double> mu(Bt * m), sg(Bt * m * m);
+    static const double dummy = 0.0;
+    ngp_job *job = nullptr;
+    ngp_status st = stage_general(c, (int)Bt, ks.data(), r0.n, r0.t, nullptr, 0, 0, &dummy, 1, &dummy, 0,
+                                  r0.m, r0.t_new, r0.noise_on_new, &job, rows.data());
+    if (st) return st;
+    st = ngp_job_run(job);
+    if (!st) st = ngp_job_fetch(job, nullptr, lm.data(), m ? mu.data() : nullptr,
+                                m ? sg.data() : nullptr, info.data());
+    ngp_job_destroy(job);
+    if (st) return st;
+    size_t b0 = 0;
+    for (ngp_comb_req *r : grp) {
+        const size_t B = (size_t)r->B;
+        if (r->logml) std::memcpy(r->logml, lm.data() + b0, 8 * B);
+        if (r->info) std::memcpy(r->info, info.data() + b0, 4 * B);
+        if (m && r->mu) std::memcpy(r->mu, mu.data() + b0 * m, 8 * B * m);
+        if (m && r->sigma) std::memcpy(r->sigma, sg.data() + b0 * m * m, 8 * B * m * m);
+        b0 += B;
+    }
+    return NGP_OK;
+}
+
+// everything one server took from `pending`: groups in order of their first member's arrival
+void comb_execute(ngp_ctx *c, const std::vector<ngp_comb_req *> &batch, int64_t stats[4]) {
+    std::vector<char> taken(batch.size(), 0);
+    for (size_t i = 0; i < batch.size(); ++i) {
+        if (taken[i]) continue;
+        std::vector<ngp_comb_req *> grp{batch[i]};
+        taken[i] = 1;
+        for (size_t j = i + 1; j < batch.size(); ++j)
+            if (!taken[j] && comb_same(*batch[i], *batch[j])) {
+                grp.push_back(batch[j]);
+                taken[j] = 1;
+            }
+        stats[0] += (int64_t)grp.size();
+        if (grp.size() > 1) {
+            const ngp_status st = comb_run_group(c, grp);
+            if (st == NGP_OK) {
+                for (ngp_comb_req *r : grp) r->st = NGP_OK;
+                stats[1] += 1;
+                stats[2] = std::max<int64_t>(stats[2], (int64_t)grp.size());
+                stats[3] += (int64_t)grp.size();
+                continue;
+            }
+        }
+        for (ngp_comb_req *r : grp) {   // alone, or the merged call failed: each for itself
+            r->st = comb_run_one(c, *r);
+            stats[1] += 1;
+            stats[2] = std::max<int64_t>(stats[2], 1);
+        }
+    }
+}
+
+// A caller that finds nobody serving, but whose predecessors came in company, gives that company
+// this long to arrive before it serves (tasks that were woken together by the previous sequence do
+// their host work and come back within microseconds of each other: without the wait the first one
+// back runs alone and the convoy alternates 1, T-1, 1, T-1 ...).  Bounded, and never paid twice in
+// vain: a wait that ends short of the expected company lowers the expectation to what did arrive,
+// so a caller that is alone waits at most once after a concurrent phase and never otherwise.
+constexpr int COMB_LINGER_US = 200;
+
+ngp_status combine_submit(ngp_ctx *c, ngp_comb_req &r) {
+    r.key = comb_key(r);   // outside the lock: 16 KB of dates at n = 2048
+    std::unique_lock<std::mutex> q(c->qmu);
+    if (!c->combine_on) {
+        q.unlock();
+        return comb_run_one(c, r);
+    }
+    c->pending.push_back(&r);
+    c->comb_arrival.notify_all();
+    // Invariant: a request that is not done is either in `pending` or in the batch of the one
+    // serving thread (combining == true).  So a thread that finds nobody serving finds its own
+    // request in `pending`.
+    while (!r.done) {
+        if (c->combining) {
+            r.cv.wait(q);
+            continue;
+        }
+        c->combining = true;
+        if (c->pending.size() < c->comb_expect) {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(COMB_LINGER_US);
+            (void)c->comb_arrival.wait_until(q, deadline, [&] { return c->pending.size() >= c->comb_expect; });
+        }
+        std::vector<ngp_comb_req *> batch;
+        batch.swap(c->pending);
+        c->comb_expect = std::max<size_t>(batch.size(), 1);
+        q.unlock();
+        int64_t stats[4] = {0, 0, 0, 0};
+        comb_execute(c, batch, stats);
+        q.lock();
+        c->comb_stats[0] += stats[0];
+        c->comb_stats[1] += stats[1];
+        c->comb_stats[2] = std::max(c->comb_stats[2], stats[2]);
+        c->comb_stats[3] += stats[3];
+        // (qmu is held from `done = true` to the notify: a woken caller cannot leave — and take its
+        // request off its stack — before this loop is through with it)
+        for (ngp_comb_req *x : batch) {
+            x->done = true;
+            if (x != &r) x->cv.notify_one();
+        }
+        c->combining = false;
+        // what arrived meanwhile is served by its first waiter, not by this thread
+        if (!c->pending.empty()) c->pending.front()->cv.notify_one();
+    }
+    return r.st;
+}
+
+}  // namespace
+
+extern "C" ngp_status ngp_set_combining(ngp_ctx *c, int32_t on) {
+    if (!c) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->qmu);
+    c->combine_on = on != 0;
+    return NGP_OK;
+}
+
+extern "C" ngp_status ngp_combine_stats(ngp_ctx *c, int64_t *out4, int32_t reset) {
+    if (!c || !out4) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->qmu);
+    for (int i = 0; i < 4; ++i) out4[i] = c->comb_stats[i];
+    if (reset) for (int i = 0; i < 4; ++i) c->comb_stats[i] = 0;
+    return NGP_OK;
+}
+
+// Arguments the merged form could not carry (null arrays, a malformed tree, empty sizes) never
+// join a group: the direct path reports them exactly as before.
+static bool comb_value_args_ok(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n, const double *t,
+                               const double *y) {
+    if (!c || !k || !t || !y || B <= 0 || n <= 0) return false;
+    for (int i = 0; i < B; ++i)
+        if (check_program(&k[i]) != NGP_OK) return false;
+    return true;
+}
+
+extern "C" ngp_status ngp_logml_batch(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
+                                      const double *t, const double *y, int64_t ldy, double *logml,
+                                      int32_t *info) {
+    if (!comb_value_args_ok(c, B, k, n, t, y)) return logml_direct(c, B, k, n, t, y, ldy, logml, info);
+    ngp_comb_req r;
+    r.kind = CK_LOGML;
+    r.B = B; r.k = k; r.n = n; r.t = t; r.y = y; r.ldy = ldy;
+    r.logml = logml; r.info = info;
+    return combine_submit(c, r);
+}
+
+extern "C" ngp_status ngp_predict_batch(ngp_ctx *c, int32_t B, const ngp_kernel *k, int32_t n,
+                                        const double *t, const double *y, int64_t ldy, int32_t m,
+                                        const double *t_new, int32_t noise_on_new, double *mu,
+                                        double *sigma, double *logml, int32_t *info) {
+    if (!comb_value_args_ok(c, B, k, n, t, y) || m <= 0 || !t_new)
+        return predict_direct(c, B, k, n, t, y, ldy, m, t_new, noise_on_new, mu, sigma, logml, info);
+    ngp_comb_req r;
+    r.kind = CK_PREDICT;
+    r.B = B; r.k = k; r.n = n; r.t = t; r.y = y; r.ldy = ldy;
+    r.m = m; r.t_new = t_new; r.noise_on_new = noise_on_new ? 1 : 0;
+    r.mu = mu; r.sigma = sigma; r.logml = logml; r.info = info;
+    return combine_submit(c, r);
+}
+
+extern "C" ngp_status ngp_logml_grad_batch(ngp_ctx *c, int32_t B, const ngp_kernel *kernels,
+                                           int32_t n, const double *t, const double *y,
+                                           int64_t ldy, double *logml, double *grad,
+                                           int32_t *info) {
+    if (!grad || !comb_value_args_ok(c, B, kernels, n, t, y))
+        return logml_grad_direct(c, B, kernels, n, t, y, ldy, nullptr, logml, grad, info);
+    ngp_comb_req r;
+    r.kind = CK_GRAD;
+    r.B = B; r.k = kernels; r.n = n; r.t = t; r.y = y; r.ldy = ldy;
+    r.logml = logml; r.grad = grad; r.info = info;
+    return combine_submit(c, r);
+}
+
+// A resident job that still has the one-shot form of its inputs (small jobs) is a gradient request
+// like any other: with company it shares one call over everybody's items, alone it runs on its
+// resident inputs.
+extern "C" ngp_status ngp_grad_job_run(ngp_grad_job *j, double *logml, double *grad, int32_t *info) {
+    if (!j || !grad) return NGP_ERR_ARG;
+    if (j->h_k.empty()) return grad_job_run_resident(j, logml, grad, info);
+    ngp_comb_req r;
+    r.kind = CK_GRAD;
+    r.gj = j;
+    r.B = j->B; r.k = j->h_k.data(); r.n = j->n; r.t = j->h_t.data();
+    r.y = j->h_y.data(); r.ldy = j->h_ldy;
+    r.logml = logml; r.grad = grad; r.info = info;
+    return combine_submit(j->ctx, r);
+}
+
+extern "C" ngp_status ngp_mixture_sample(ngp_ctx *c, int32_t P, int32_t S, int32_t m,
+                                         const double *w, const double *mu, const double *sigma,
+                                         int32_t draws, uint64_t seed, double *out, int32_t *comp,
+                                         int32_t *info) {
+    // S mixtures over shared components stay one call of their own; ONE mixture (what
+    // predict_mvn(...) |> rand of a scenario task asks for, src/forecasting.jl:46-47) can share a
+    // launch with other tasks' mixtures of the same shape
+    if (S != 1 || !c || !w || !mu || !sigma || !out || P <= 0 || m <= 0 || m > NGP_MAX_AUX || draws <= 0)
+        return mixture_sample_impl(c, P, S, m, w, mu, sigma, draws, seed, nullptr, out, comp, info);
+    ngp_comb_req r;
+    r.kind = CK_MIXTURE;
+    r.P = P; r.m = m; r.draws = draws; r.w = w;
+    r.cmu = mu; r.csigma = sigma;
+    r.seed = seed; r.out = out; r.comp = comp; r.info = info;
+    return combine_submit(c, r);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2525,6 +2957,11 @@ struct ngp_comm {
     ngp_ctx *ctx = nullptr;
     void *comm = nullptr;
     int rank = 0, world = 1;
+    // send / receive buffers of the all-gather, grow-only: after the first call of a shape no
+    // rank allocates inside a collective (an allocation that fails on ONE rank would leave its
+    // peers waiting in the all-gather)
+    void *d_send = nullptr, *d_recv = nullptr;
+    size_t cap = 0;   // doubles per rank
 };
 
 extern "C" ngp_status ngp_comm_unique_id(void *id128) {
@@ -2550,19 +2987,17 @@ extern "C" ngp_status ngp_comm_create(ngp_ctx *c, const void *id128, int32_t ran
     m->ctx = c;
     m->rank = rank;
     m->world = world;
-    // RCCL allocates its own device buffers: after a large job most of the device can sit in the
-    // caching allocators of this process, so a failed initialisation is tried once more with the
-    // caches given back
+    // RCCL allocates its own device buffers, and after a large job most of the device can sit in
+    // the caching allocators of this process: they are given back BEFORE the one attempt.  (The
+    // initialisation is a collective — a rank that retried it alone after a failure would pair
+    // with nobody, its peers having returned from the first attempt or still waiting inside it.)
+    c->drop_cache();
+    c->ws_drop();
+    ngp_ctx::drop_other_caches(c);
     if (rccl().CommInitRank(&m->comm, world, uid, rank) != 0) {
         (void)hipGetLastError();
-        c->drop_cache();
-        ngp_ctx::drop_other_caches(c);
-        m->comm = nullptr;
-        if (rccl().CommInitRank(&m->comm, world, uid, rank) != 0) {
-            (void)hipGetLastError();
-            delete m;
-            return NGP_ERR_UNAVAILABLE;
-        }
+        delete m;
+        return NGP_ERR_UNAVAILABLE;
     }
     *out = m;
     return NGP_OK;
@@ -2574,6 +3009,11 @@ extern "C" void ngp_comm_destroy(ngp_comm *m) {
         (void)hipSetDevice(m->ctx->device);
         (void)rccl().CommDestroy(m->comm);
     }
+    {
+        std::lock_guard<std::mutex> lk(m->ctx->mu);
+        m->ctx->release(m->d_send);
+        m->ctx->release(m->d_recv);
+    }
     delete m;
 }
 
@@ -2583,6 +3023,28 @@ extern "C" ngp_status ngp_shard(int32_t P_total, int32_t world, int32_t rank, in
     const int base = P_total / world, rem = P_total % world;
     if (first) *first = rank * base + std::min(rank, rem);
     if (rows) *rows = base + (rank < rem ? 1 : 0);
+    return NGP_OK;
+}
+
+// The host half of the exchange: `padded` holds what an all-gather of equally sized, zero-padded
+// shards delivers — world blocks of pmax x D doubles, pmax = the largest shard (rank 0's), block r =
+// rank r's rows then padding — and comes out as the P_total x D normalised weights.  Exported so that
+// a host with a collective of its own (MPI.jl, Julia's Distributed, torch.distributed) pads,
+// gathers with that, and normalises exactly as ngp_weights_allgather_normalize does.
+extern "C" ngp_status ngp_weights_unpad_normalize(int32_t P_total, int32_t world, int32_t D,
+                                                  const double *padded, double *w_all, double *ess,
+                                                  double *log_norm) {
+    if (!padded || P_total <= 0 || D <= 0 || world <= 0 || P_total < world) return NGP_ERR_ARG;
+    auto rows_of = [&](int r) { int32_t v = 0; (void)ngp_shard(P_total, world, r, nullptr, &v); return (size_t)v; };
+    auto first_of = [&](int r) { int32_t v = 0; (void)ngp_shard(P_total, world, r, &v, nullptr); return (size_t)v; };
+    const size_t cnt = rows_of(0) * (size_t)D;
+    std::vector<double> lw((size_t)P_total * D), wn((size_t)P_total * D);
+    for (int r = 0; r < world; ++r)
+        std::memcpy(lw.data() + first_of(r) * D, padded + (size_t)r * cnt, 8 * rows_of(r) * D);
+    for (int sidx = 0; sidx < D; ++sidx)
+        weights_normalize_strided(P_total, lw.data() + sidx, D, wn.data() + sidx, D,
+                                  ess ? ess + sidx : nullptr, log_norm ? log_norm + sidx : nullptr);
+    if (w_all) std::memcpy(w_all, wn.data(), 8 * wn.size());
     return NGP_OK;
 }
 
@@ -2600,14 +3062,26 @@ extern "C" ngp_status ngp_weights_allgather_normalize(ngp_comm *m, int32_t P_tot
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    // ragged shards: every rank sends pmax rows (its own, then padding)
+    // ragged shards: every rank sends pmax rows (its own, then padding).  The buffers stay with the
+    // communicator; every rank sees the same (P_total, D), so they grow on all ranks in the same
+    // call — and a rank that cannot grow them has left the collective for good: any non-zero
+    // return of this function is FATAL for the communicator (its peers may be inside the
+    // all-gather), destroy it and start over.
     const size_t cnt = (size_t)pmax * D;
-    void *d_send = nullptr, *d_recv = nullptr;
-    ngp_status st;
-    if ((st = c->alloc(&d_send, 8 * cnt)) || (st = c->alloc(&d_recv, 8 * cnt * (size_t)m->world))) {
-        c->release(d_send);
-        return st;
+    if (cnt > m->cap) {
+        void *a = nullptr, *b = nullptr;
+        ngp_status st;
+        if ((st = c->alloc(&a, 8 * cnt)) || (st = c->alloc(&b, 8 * cnt * (size_t)m->world))) {
+            c->release(a);
+            return st;
+        }
+        c->release(m->d_send);
+        c->release(m->d_recv);
+        m->d_send = a;
+        m->d_recv = b;
+        m->cap = cnt;
     }
+    void *d_send = m->d_send, *d_recv = m->d_recv;
     std::vector<double> h_all(cnt * (size_t)m->world);
     hipError_t e = hipMemsetAsync(d_send, 0, 8 * cnt, s);
     if (e == hipSuccess)
@@ -2617,18 +3091,12 @@ extern "C" ngp_status ngp_weights_allgather_normalize(ngp_comm *m, int32_t P_tot
     if (e == hipSuccess && rc == 0)
         e = hipMemcpyAsync(h_all.data(), d_recv, 8 * h_all.size(), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && rc == 0) e = hipStreamSynchronize(s);
-    c->release(d_send);
-    c->release(d_recv);
     if (rc != 0) return NGP_ERR_UNAVAILABLE;
     if (e != hipSuccess) return (ngp_status)e;
     // compact the padded shards to [P_total x D], then the columns as ngp_weights_normalize_cols
-    std::vector<double> lw((size_t)P_total * D), wn((size_t)P_total * D);
-    for (int r = 0; r < m->world; ++r)
-        std::memcpy(lw.data() + (size_t)first_of(r) * D, h_all.data() + (size_t)r * cnt,
-                    8 * (size_t)rows_of(r) * D);
-    for (int sidx = 0; sidx < D; ++sidx)
-        weights_normalize_strided(P_total, lw.data() + sidx, D, wn.data() + sidx, D,
-                                  ess ? ess + sidx : nullptr, log_norm ? log_norm + sidx : nullptr);
+    std::vector<double> wn((size_t)P_total * D);
+    const ngp_status st = ngp_weights_unpad_normalize(P_total, m->world, D, h_all.data(), wn.data(), ess, log_norm);
+    if (st) return st;
     if (w_all) std::memcpy(w_all, wn.data(), 8 * wn.size());
     if (w_local)
         std::memcpy(w_local, wn.data() + (size_t)first_of(m->rank) * D, 8 * (size_t)mine * D);

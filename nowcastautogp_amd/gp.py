@@ -347,7 +347,7 @@ class FlatTransform:
 def untransform_flat(theta: np.ndarray, codes: np.ndarray, prior) -> np.ndarray:
     """``untransform`` for many particles at once (``theta`` / ``codes``: concatenation over
     particles, ``KIND_CODES``): the inverse maps of ``transform_flat``."""
-    theta = np.asarray(theta, dtype=np.float64)
+    theta = clip_flat(np.array(theta, dtype=np.float64), codes)
     z = np.empty_like(theta)
     m = codes == 0
     z[m] = theta[m]
@@ -365,6 +365,23 @@ def untransform_flat(theta: np.ndarray, codes: np.ndarray, prior) -> np.ndarray:
             pr = prior[name]
             z[m] = (np.log(theta[m]) - pr["mu"]) / pr["sigma"]
     return z
+
+
+def clip_flat(theta: np.ndarray, codes: np.ndarray) -> np.ndarray:
+    """Parameters kept strictly inside the open domain of their kind (in place; the margins the
+    HMC potential uses): a value that saturated in double precision — gamma == 2.0, a unit
+    parameter == 1.0, a positive one == 0 — has an infinite latent, and a particle carrying one is
+    frozen (every later move has H = inf and is rejected) without any error."""
+    m = (codes == 3) | (codes == 4)
+    if m.any():
+        theta[m] = np.clip(theta[m], 1e-12, 1e300)
+    m = codes == 2
+    if m.any():
+        theta[m] = np.clip(theta[m], 1e-9, 2.0 - 1e-9)
+    m = codes == 1
+    if m.any():
+        theta[m] = np.clip(theta[m], 1e-9, 1.0 - 1e-9)
+    return theta
 
 
 NOISE_KIND = "wildcard"

@@ -150,8 +150,9 @@ def forecast_lockstep(models: Sequence[GPModel], forecast_dates, forecast_draws:
         out = autogp.rand_lockstep(mixes, k, models[0]._eng())
     else:
         out = [np.empty((len(dates), k)) for _ in models]
+        obs = None               # the models' data does not change between the draws
         for i in range(k):       # src/forecasting.jl:63-68: HMC on the parameters before every draw
-            autogp.mcmc_parameters_lockstep(models, forecast_n_hmc, hmc_config)
+            obs = autogp.mcmc_parameters_lockstep(models, forecast_n_hmc, hmc_config, obs)
             for o, mix in zip(out, autogp.predict_mvn_lockstep(models, dates)):
                 o[:, i] = mix.rand()
     return [_apply(inv_transformation, o) for o in out]
@@ -162,10 +163,14 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
                            inv_transformation: Callable = lambda y: y, n_mcmc: int = 0,
                            n_hmc: int = 0, ess_threshold: float = 0.0,
                            forecast_n_hmc: Optional[int] = None, verbose: bool = False,
-                           lockstep: bool = True, hmc_config: Optional[dict] = None) -> np.ndarray:
-    """reference src/forecasting.jl:117-167.  Two keywords are this module's own: ``lockstep``
-    (False: the reference's per-scenario loop, one clone after another) and ``hmc_config``
-    (leapfrog count / step size of the refinement moves; AutoGP's defaults apply in the reference)."""
+                           lockstep: bool = True, hmc_config: Optional[dict] = None,
+                           threads: Optional[int] = None) -> np.ndarray:
+    """reference src/forecasting.jl:117-167.  Three keywords are this module's own: ``lockstep``
+    (False: the reference's per-scenario loop), ``threads`` (with ``lockstep=False``: the loop's
+    scenarios as concurrent tasks on that many threads — the reference's ``Threads.@spawn`` per
+    scenario, src/forecasting.jl:131-132; the library combines their calls, include/ngp.h
+    "concurrent callers") and ``hmc_config`` (leapfrog count / step size of the refinement moves;
+    AutoGP's defaults apply in the reference)."""
     assert len(nowcasts) > 0, "nowcasts vector must not be empty"
     assert not (n_mcmc > 0 and n_hmc == 0), \
         "If n_mcmc > 0, n_hmc must also be > 0 for MCMC refinement"
@@ -199,17 +204,34 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
         if verbose:
             print(f"Nowcast scenarios: {len(results)}/{len(nowcasts)} (lockstep)")
         return np.hstack(results)
-    results = []
-    for nc in nowcasts:   # the reference's per-scenario task, one after another
-        m = clone()
+    def task(m, nc):      # the body of the reference's per-scenario task (src/forecasting.jl:133-155)
         autogp.add_data(m, nc.ds, nc.y)
         autogp.maybe_resample(m, ess_threshold * autogp.num_particles(m))
         if n_mcmc > 0 and n_hmc > 0:
             autogp.mcmc_structure(m, n_mcmc, n_hmc, hmc_config)
         elif n_mcmc == 0 and n_hmc > 0:
             autogp.mcmc_parameters(m, n_hmc, hmc_config)
-        results.append(forecast(m, dates, draws, inv_transformation=inv_transformation,
-                                forecast_n_hmc=forecast_n_hmc, hmc_config=hmc_config))
+        return forecast(m, dates, draws, inv_transformation=inv_transformation,
+                        forecast_n_hmc=forecast_n_hmc, hmc_config=hmc_config)
+
+    if threads is not None and int(threads) > 1 and len(nowcasts) > 1 and autogp.distributed.world()[1] == 1:
+        # Threads.@spawn per scenario (src/forecasting.jl:131-132).  The clones are made in scenario
+        # order first (each takes its root from the base model's shared stream), then every task
+        # works on its own clone with its own streams: the result does not depend on the schedule
+        # beyond the last bits the library's batching decides.  A clone forecasts ONCE, so its
+        # predictive call is the one-shot entry point (combinable), not a resident factor.
+        from concurrent.futures import ThreadPoolExecutor
+        models = [clone() for _ in nowcasts]
+        for m in models:
+            m._one_shot_predict = True
+        with ThreadPoolExecutor(max_workers=int(threads)) as pool:
+            results = list(pool.map(task, models, nowcasts))
+        if verbose:
+            print(f"Nowcast scenarios: {len(results)}/{len(nowcasts)} ({int(threads)} threads)")
+        return np.hstack(results)
+    results = []
+    for nc in nowcasts:   # one after another
+        results.append(task(clone(), nc))
         if verbose:
             print(f"Nowcast scenarios: {len(results)}/{len(nowcasts)}")
     return np.hstack(results)

@@ -158,10 +158,31 @@ def validate(d: Dict[str, Any]) -> None:
             raise ValueError(f"config lacks {k}")
 
 
+def check_spec(engine, spec) -> bool:
+    """Raise if ``spec`` (the ``spec`` entry of a snapshot, or None) differs from what ``engine``
+    runs; False when there is nothing to compare yet (no engine, an engine without a context)."""
+    if engine is None or not hasattr(engine, "ctx") or spec is None:
+        return False
+    sp = engine.ctx.get_spec()
+    have = dict(se_form=int(sp.se_form), periodic_form=int(sp.periodic_form),
+                cp_form=int(sp.cp_form), jitter=float(sp.jitter))
+    want = {k: dict(spec).get(k) for k in have}
+    if any(want[k] is not None and want[k] != have[k] for k in have):
+        raise ValueError(f"ngp-model dict was written under spec {want}, the engine runs {have}: "
+                         "load it with an engine of the same spec (ngp_set_spec)")
+    return True
+
+
 def model_from_wire(model, d: Dict[str, Any]) -> None:
     """Fill a blank GPModel from a validated dict (GPModel._load)."""
     from . import autogp, gp
     validate(d)
+    # the cached per-particle logml belongs to the formula variants / jitter it was computed under:
+    # under another spec the next weight update (logml(n+d) - logml(n)) would mix two
+    # parametrisations, so a snapshot is only loaded under the spec that wrote it.  Checked before
+    # anything is assigned when the model already has its engine, else at the first use of the
+    # engine (GPModel._eng: the default HipEngine is made lazily).
+    checked = check_spec(getattr(model, "engine", None), d.get("spec"))
     model.config = config_from_wire(d["config"])
     model.ds = _ds_from_wire(d["data"]["ds_kind"], d["data"]["ds"])
     model.y = np.array(d["data"]["y"], dtype=np.float64)
@@ -179,19 +200,8 @@ def model_from_wire(model, d: Dict[str, Any]) -> None:
     model.n_obs = int(d["n_obs"])
     model._perm = np.array(d["perm"], dtype=np.int64)
     model._logml = np.array(d["logml"], dtype=np.float64)
-    model.wire_spec = dict(d["spec"])
-    # the cached per-particle logml belongs to the formula variants / jitter it was computed under:
-    # under another spec the next weight update (logml(n+d) - logml(n)) would mix two
-    # parametrisations, so a snapshot is only loaded under the spec that wrote it
-    eng = getattr(model, "engine", None)
-    if eng is not None and hasattr(eng, "ctx") and d["spec"] is not None:
-        sp = eng.ctx.get_spec()
-        have = dict(se_form=int(sp.se_form), periodic_form=int(sp.periodic_form),
-                    cp_form=int(sp.cp_form), jitter=float(sp.jitter))
-        want = {k: d["spec"].get(k) for k in have}
-        if any(want[k] is not None and want[k] != have[k] for k in have):
-            raise ValueError(f"ngp-model dict was written under spec {want}, the engine runs {have}: "
-                             "load it with an engine of the same spec (ngp_set_spec)")
+    model.wire_spec = dict(d["spec"]) if d.get("spec") is not None else None
+    model._spec_checked = checked or d.get("spec") is None
     rng = d.get("rng")
     if rng and rng.get("kind") == "numpy-pcg64" and len(rng["particles"]) == len(model.particles):
         model._root, model._gen = int(rng["root"]), int(rng["generation"])

@@ -7,10 +7,12 @@
 // lifetimes, the staging code, the error paths — entered from several threads at once.
 // Nothing here is part of the product; libngp.so never links it.
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 extern "C" {
@@ -21,7 +23,7 @@ struct dim3_ { uint32_t x, y, z; };
 
 static std::mutex g_mu;
 static std::unordered_map<void *, size_t> g_live;      // allocation -> bytes
-static std::atomic<long> g_launches{0}, g_bad_free{0}, g_oob{0};
+static std::atomic<long> g_launches{0}, g_bad_free{0}, g_oob{0}, g_sync_us{0};
 
 static bool inside(const void *p, size_t n) {
     // host pointers (stack / heap of the caller) are not tracked: only check "device" ones
@@ -68,7 +70,13 @@ hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
 }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return 0; }
 hipError_t hipStreamDestroy(hipStream_t s) { free(s); return 0; }
-hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+// a "busy device": every synchronisation takes mock_hip_set_sync_delay_us microseconds, so that
+// concurrent callers pile up behind the one that holds the context (combine_stress.cpp)
+hipError_t hipStreamSynchronize(hipStream_t) {
+    const long us = g_sync_us.load();
+    if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us));
+    return 0;
+}
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return 0; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
@@ -94,6 +102,7 @@ void __hipRegisterVar(void **, void *, char *, const char *, int, size_t, int, i
 
 // for the driver
 long mock_hip_launches(void) { return g_launches.load(); }
+void mock_hip_set_sync_delay_us(long us) { g_sync_us.store(us); }
 long mock_hip_live_allocations(void) { std::lock_guard<std::mutex> lk(g_mu); return (long)g_live.size(); }
 long mock_hip_errors(void) { return g_bad_free.load() + g_oob.load(); }
 }

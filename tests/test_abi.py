@@ -90,6 +90,33 @@ def test_weights_normalize_cols_equals_the_column_by_column_call(lib):
     assert np.array_equal(w[:, 0], w_ref) and ess[0] == ess_ref
 
 
+@pytest.mark.parametrize("P_total,world", [(7, 3), (8, 4), (5, 5), (11, 2), (3, 1)])
+def test_unpad_normalize_is_the_world_size_n_half_of_the_collective(lib, P_total, world):
+    """The part of ngp_weights_allgather_normalize that only exists with more than one rank —
+    ragged shards padded to the largest, gathered, compacted — as a host function: built here from
+    ngp_shard's partition exactly as every rank fills its send buffer, it must give what
+    ngp_weights_normalize_cols gives on the unsharded matrix (P_total not divisible by world)."""
+    rng = np.random.default_rng(P_total * 10 + world)
+    D = 4
+    lw = -300.0 + 3.0 * rng.standard_normal((P_total, D))
+    lw[0, 1] = -np.inf
+    pmax = _lib.shard(P_total, world, 0)[1]
+    padded = np.zeros((world, pmax, D))
+    seen = 0
+    for r in range(world):
+        first, rows = _lib.shard(P_total, world, r)
+        assert first == seen and 1 <= rows <= pmax
+        padded[r, :rows] = lw[first:first + rows]
+        seen += rows
+    assert seen == P_total
+    w, ess, ln = _lib.weights_unpad_normalize(padded, P_total, world)
+    w_ref, ess_ref, ln_ref = _lib.weights_normalize_cols(lw)
+    assert np.array_equal(w, w_ref) and np.array_equal(ess, ess_ref) and np.array_equal(ln, ln_ref)
+    # fewer particles than ranks: refused (every rank must own a row), as the collective refuses it
+    with pytest.raises(_lib.NgpError):
+        _lib.weights_unpad_normalize(np.zeros((world + 1, 1, D)), world, world + 1)
+
+
 def test_rccl_entry_points_answer_cleanly_without_a_gpu(lib):
     """ngp_comm_* open librccl at run time; without a usable device (this container) they answer
     with a status instead of crashing or hanging."""

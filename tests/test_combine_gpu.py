@@ -1,0 +1,203 @@
+"""Concurrent callers (include/ngp.h "concurrent callers"): the reference enters the boundary from
+one task per nowcast scenario (Threads.@spawn, reference src/forecasting.jl:131-159).  Eight host
+threads (ctypes drops the GIL for the duration of a call) enter the one-shot entry points at once;
+the library combines them into few launch sequences.  Checked against the same calls made one after
+another with combining off, and against the CPU oracle."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from nowcastautogp_amd import _lib, autogp
+from nowcastautogp_amd import nowcast as nc
+from nowcastautogp_amd._abi import KernelArray
+from nowcastautogp_amd.synthetic import make_ensemble, make_workload
+from oracle import oracle_np
+from tests import mirror_contracts as mc
+from tests.util import TOL_LOGML, TOL_PRED, check, nerr
+
+pytestmark = pytest.mark.gpu
+T = 8
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import __graft_entry__ as ge
+    ge.build()
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _tasks(n, P, seed):
+    """T scenario tasks on the same dates: their own trees, their own last observation."""
+    w = make_workload("C3", n=n, P=P, D=T, d=1, m=5, seed_offset=seed)
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    t = np.concatenate([w.t, w.t_add])
+    out = []
+    for s in range(T):
+        progs = make_ensemble(rng, P, depth_cap=3)
+        y = np.concatenate([w.y, w.y_add[s]])
+        out.append((progs, y))
+    return t, w.t_new, out
+
+
+def _burst(fn, tasks):
+    """every task's call from its own thread, all released together; (results, wall seconds)"""
+    res = [None] * len(tasks)
+    gate = threading.Barrier(len(tasks) + 1)
+
+    def work(i):
+        gate.wait()
+        res[i] = fn(*tasks[i])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(tasks))]
+    for x in th:
+        x.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for x in th:
+        x.join()
+    return res, time.perf_counter() - t0
+
+
+@pytest.mark.parametrize("n,P", [(208, 24), (2048, 64)], ids=["n208x24", "n2048x64"])
+def test_concurrent_gradient_calls_share_launch_sequences(ctx, n, P):
+    t, _, tasks = _tasks(n, P, seed=n)
+    kas = [KernelArray(p) for p, _ in tasks]
+
+    def call(i):
+        return ctx.logml_grad_flat(kas[i], t, tasks[i][1])
+
+    # one after another, combining off: the reference point for results, launches and time
+    ctx.set_combining(False)
+    for i in range(T):
+        call(i)                                   # warm-up (allocator, workspace)
+    serial_s = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        serial = [call(i) for i in range(T)]
+        serial_s = min(serial_s, time.perf_counter() - t0)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for i in range(T):
+        call(i)
+    launches_serial = int(sum(v["launches"] for v in ctx.profile_get().values()))
+    ctx.profile_enable(False)
+    # the same T calls from T threads at once; a first burst warms the larger shapes up
+    ctx.set_combining(True)
+    _burst(lambda i: call(i), [(i,) for i in range(T)])
+    comb_s = 1e9
+    for _ in range(3):
+        comb, dt = _burst(lambda i: call(i), [(i,) for i in range(T)])
+        comb_s = min(comb_s, dt)
+    ctx.combine_stats(reset=True)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    comb, _ = _burst(lambda i: call(i), [(i,) for i in range(T)])
+    launches_comb = int(sum(v["launches"] for v in ctx.profile_get().values()))
+    ctx.profile_enable(False)
+    st = ctx.combine_stats(reset=True)
+    print(f"n={n} P={P}: serial {serial_s * 1e3:.2f} ms / {launches_serial} launches, combined "
+          f"{comb_s * 1e3:.2f} ms / {launches_comb} launches, {st}")
+    assert st["requests"] == T and st["sequences"] <= 3 and st["largest_group"] >= T - 2
+    # about one combined call's launches (a split batch runs two leaves), not T calls'
+    assert launches_comb <= 0.6 * launches_serial, (launches_comb, launches_serial)
+    for i in range(T):
+        lm_s, g_s, info_s = serial[i]
+        lm_c, g_c, info_c = comb[i]
+        assert not info_s.any() and not info_c.any()
+        check("combined vs serial logml", lm_c, lm_s, TOL_LOGML)
+        # gradients: per item relative to the item's largest component
+        off = np.concatenate([[0], np.cumsum(kas[i]._npar + 1)])
+        for b in range(P):
+            sl = slice(off[b], off[b + 1])
+            check("combined vs serial gradient", g_c[sl], g_s[sl], 1e-7)
+    # the oracle on the first and last task's first items
+    for i in (0, T - 1):
+        progs, y = tasks[i]
+        for b in (0, P - 1):
+            lm_o, g_o, info_o = oracle_np.logml_grad(progs[b], t, y)
+            assert info_o == 0
+            off = np.concatenate([[0], np.cumsum(kas[i]._npar + 1)])
+            cond = float(np.linalg.cond(oracle_np.cov(progs[b], t, t, add_diag=True)))
+            check("combined logml vs oracle", comb[i][0][b], lm_o, TOL_LOGML, cond)
+            check("combined gradient vs oracle", comb[i][1][off[b]:off[b + 1]], g_o, 1e-7, cond)
+    if n == 208:      # the everyday size: a call there is a chain of short dependent launches
+        assert comb_s <= 0.4 * serial_s, (comb_s, serial_s)
+
+
+def test_concurrent_value_calls_and_mixtures(ctx):
+    """logml, predict and the one-mixture sampler from T threads at once: every caller gets what
+    its own call returns (draws exactly: the Philox stream is keyed by the caller's seed)."""
+    t, t_new, tasks = _tasks(300, 12, seed=7)
+    ctx.set_combining(False)
+    ser_l = [ctx.logml_batch(p, t, y) for p, y in tasks]
+    ser_p = [ctx.predict_batch(p, t, y, t_new) for p, y in tasks]
+    w = np.full((1, 12), 1.0 / 12)
+    ser_m = [ctx.mixture_sample(w, ser_p[i][0][:, None, :], ser_p[i][1], 40, 77 + i) for i in range(T)]
+    ctx.set_combining(True)
+    ctx.combine_stats(reset=True)
+    com_l, _ = _burst(lambda p, y: ctx.logml_batch(p, t, y), tasks)
+    com_p, _ = _burst(lambda p, y: ctx.predict_batch(p, t, y, t_new), tasks)
+    com_m, _ = _burst(lambda i: ctx.mixture_sample(w, ser_p[i][0][:, None, :], ser_p[i][1], 40, 77 + i),
+                      [(i,) for i in range(T)])
+    st = ctx.combine_stats(reset=True)
+    print("value calls:", st)
+    assert st["requests"] == 3 * T and st["shared"] >= T
+    for i in range(T):
+        assert not com_l[i][1].any() and not com_p[i][3].any()
+        check("combined vs serial logml", com_l[i][0], ser_l[i][0], TOL_LOGML)
+        check("combined vs serial predictive mean", com_p[i][0], ser_p[i][0], TOL_PRED)
+        check("combined vs serial predictive covariance", com_p[i][1], ser_p[i][1], TOL_PRED)
+        check("combined vs serial logml", com_p[i][2], ser_p[i][2], TOL_LOGML)
+        assert np.array_equal(com_m[i][1], ser_m[i][1])          # component picks
+        assert np.array_equal(com_m[i][0], ser_m[i][0])          # draws
+
+
+def test_resident_job_runs_combine_and_different_dates_do_not(ctx):
+    t, _, tasks = _tasks(256, 8, seed=3)
+    t2 = t * 1.000001                                 # other dates: never the same group
+    kas = [KernelArray(p) for p, _ in tasks]
+    ctx.set_combining(False)
+    serial = [ctx.logml_grad_flat(kas[i], t if i % 2 == 0 else t2, tasks[i][1]) for i in range(T)]
+    ctx.set_combining(True)
+    jobs = [ctx.stage_grad(kas[i], t if i % 2 == 0 else t2, tasks[i][1]) for i in range(T)]
+    ctx.combine_stats(reset=True)
+    comb, _ = _burst(lambda i: jobs[i].run(), [(i,) for i in range(T)])
+    st = ctx.combine_stats(reset=True)
+    print("resident jobs, two sets of dates:", st)
+    assert st["requests"] == T and st["largest_group"] <= T // 2
+    for i in range(T):
+        check("combined job run vs serial logml", comb[i][0], serial[i][0], TOL_LOGML)
+        check("combined job run vs serial gradient", comb[i][1], serial[i][1], 1e-7)
+        jobs[i].close()
+
+
+def test_threaded_per_scenario_loop_is_the_reference_flow(ctx):
+    """forecast_with_nowcasts as the reference runs it — one task per scenario, each making its own
+    P-item calls — on T threads: same draws as the loop run one scenario after another (to the
+    last bits batching decides), and the tasks' calls were combined."""
+    eng = autogp.HipEngine.__new__(autogp.HipEngine)
+    eng.ctx = ctx
+    n = 150
+    vals = 100.0 + 0.3 * np.arange(n) + 3.0 * np.sin(np.arange(n) / 7.0) \
+        + np.random.default_rng(5).standard_normal(n)
+    base = mc.fitted(eng, values=vals, seed=41, n_particles=4, n_mcmc=1, n_hmc=1,
+                     smc_data_proportion=0.5)
+    snap = base.to_dict()
+    import copy
+    scen = nc.create_nowcast_data([[146.0 + 0.3 * k, 147.5 - 0.2 * k] for k in range(T)],
+                                  mc.days(n, n + 2))
+    dates = mc.days(n + 2, n + 8)
+    a = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=eng), scen, dates,
+                                  6, lockstep=False, n_hmc=2)
+    ctx.combine_stats(reset=True)
+    b = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=eng), scen, dates,
+                                  6, lockstep=False, n_hmc=2, threads=T)
+    st = ctx.combine_stats(reset=True)
+    print("threaded per-scenario loop:", st, "max rel diff", np.max(np.abs(a - b) / np.abs(a)))
+    assert a.shape == b.shape == (6, 6 * T) and np.isfinite(b).all()
+    assert np.allclose(a, b, rtol=1e-9, atol=1e-9)
+    assert st["shared"] > 0 and st["sequences"] < st["requests"]

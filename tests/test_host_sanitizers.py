@@ -4,7 +4,10 @@ ThreadSanitizer, and again with AddressSanitizer + UBSan, linked against a mock 
 (tests/sanitize/mock_hip.cpp: zeroed host memory for device memory, inert streams and events,
 launches that do nothing) and driven by tests/sanitize/host_stress.cpp: four threads on one context
 plus one thread creating and destroying contexts, specs flipped between calls, staged jobs, resident
-factors, error returns.  No GPU is involved (GPU sanitizers are not available on this pool)."""
+factors, error returns — and by tests/sanitize/combine_stress.cpp: bursts of concurrent one-shot
+callers behind a "busy device" (the mock's synchronisation sleeps), i.e. the flat combining of
+include/ngp.h "concurrent callers": no lost wake-up, every caller's arrays written, a burst costs
+about one call's launches.  No GPU is involved (GPU sanitizers are not available on this pool)."""
 import os
 import shutil
 import subprocess
@@ -17,7 +20,7 @@ SAN = os.path.join(ROOT, "tests", "sanitize")
 HIPCC = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
 
 
-def build(tmp, flags, tag):
+def build(tmp, flags, tag, driver="host_stress"):
     objs = []
     for src in ("ngp_api", "ngp_kernels"):
         o = os.path.join(tmp, f"{src}_{tag}.o")
@@ -33,12 +36,12 @@ def build(tmp, flags, tag):
         for name in fat:
             f.write(f"const char {name}[16] = {{0}};\n")
     clangxx = "/opt/rocm/lib/llvm/bin/clang++"
-    for src in (os.path.join(SAN, "mock_hip.cpp"), os.path.join(SAN, "host_stress.cpp"), stub):
+    for src in (os.path.join(SAN, "mock_hip.cpp"), os.path.join(SAN, driver + ".cpp"), stub):
         o = os.path.join(tmp, os.path.basename(src).rsplit(".", 1)[0] + f"_{tag}.o")
         lang = ["-x", "c"] if src.endswith(".c") else ["-std=c++17"]
         subprocess.check_call([clangxx, *lang, "-O1", "-g", "-w", *flags, "-c", src, "-o", o])
         objs.append(o)
-    exe = os.path.join(tmp, f"host_stress_{tag}")
+    exe = os.path.join(tmp, f"{driver}_{tag}")
     subprocess.check_call([clangxx, *flags, *objs, "-lpthread", "-o", exe])
     return exe
 
@@ -49,8 +52,9 @@ def build(tmp, flags, tag):
     ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
      {"ASAN_OPTIONS": "detect_leaks=1", "UBSAN_OPTIONS": "print_stacktrace=1"}),
 ])
-def test_host_layer_under_sanitizers(tmp_path, tag, flags, env):
-    exe = build(str(tmp_path), flags, tag)
+@pytest.mark.parametrize("driver", ["host_stress", "combine_stress"])
+def test_host_layer_under_sanitizers(tmp_path, tag, flags, env, driver):
+    exe = build(str(tmp_path), flags, tag, driver)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600,
                          env={**os.environ, **env})
     report = out.stdout[-3000:] + out.stderr[-6000:]

@@ -291,6 +291,30 @@ def test_lockstep_scenarios_equal_the_per_scenario_loop(mode):
     assert all(c[1] == P and c[2] == 1 for c in calls_seq if c[0] == "logml_grad")
 
 
+@pytest.mark.parametrize("mode", [dict(n_hmc=1), dict(n_mcmc=1, n_hmc=1, ess_threshold=1.0),
+                                  dict(forecast_n_hmc=1)],
+                         ids=lambda m: ",".join(f"{k}={v}" for k, v in m.items()))
+def test_scenario_tasks_on_threads_equal_the_loop(mode):
+    """The reference runs its scenarios as concurrent tasks (Threads.@spawn, reference
+    src/forecasting.jl:131-132).  ``threads=T`` does the same with the mirror's per-scenario loop:
+    every clone has its own streams and the clones are made in scenario order, so on a
+    deterministic engine the draws are those of the loop run one scenario after another, whatever
+    the schedule."""
+    import copy
+    eng = _NoSharedK()
+    base = mc.fitted(eng, seed=33, n_particles=3)
+    snap = base.to_dict()
+    scen = nc.create_nowcast_data([[101.0, 102.5], [99.0, 104.0], [103.0, 100.5], [100.0, 100.0],
+                                   [98.5, 101.0]], mc.days(20, 22))
+    dates = mc.days(22, 26)
+    a = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=eng), scen, dates,
+                                  5, lockstep=False, **mode)
+    b = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=eng), scen, dates,
+                                  5, lockstep=False, threads=3, **mode)
+    assert a.shape == b.shape == (4, 25)
+    assert np.array_equal(a, b)
+
+
 def test_lockstep_with_the_shared_factor_weight_update(eng):
     """With a shared-K entry point the D weight updates of add_data! come from ONE query of the
     base model (P factorisations, not P x D); same draws as the loop up to rounding."""
