@@ -301,6 +301,48 @@ def fit_forecast_wallclock(w, device, rank, args):
     legs["forecast_with_nowcasts_hmc"]["items_per_gradient_call"] = (
         grad_calls[0]["items"] // grad_calls[0]["calls"] if grad_calls else 0)
     legs["forecast_with_nowcasts_hmc"]["finite_and_shaped"] = ok_h
+    # ---- the same forecast the way the reference runs it, UNCHANGED: one task per scenario
+    #      (Threads.@spawn, src/forecasting.jl:131-159), each making its own P-item calls; the
+    #      library combines concurrent callers (include/ngp.h "concurrent callers") ----
+    if not args.no_threads_leg:
+        thr = args.scenario_threads
+        eng.ctx.combine_stats(reset=True)
+        ft = timed("forecast_with_nowcasts_hmc_threads",
+                   lambda: nc.forecast_with_nowcasts(model, scen, fdates, 20, n_hmc=2, hmc_config=hmc,
+                                                     lockstep=False, threads=thr),
+                   settings={"n_hmc": 2, "hmc_config": hmc, "scenarios": D, "particles": P,
+                             "draws_per_scenario": 20, "lockstep": False, "threads": thr})
+        lt = legs["forecast_with_nowcasts_hmc_threads"]
+        lt["combining"] = eng.ctx.combine_stats(reset=True)
+        lt["finite_and_shaped"] = bool(np.isfinite(ft).all()) and ft.shape == (m, D * 20)
+        lt["over_lockstep"] = lt["gpu_s"] / legs["forecast_with_nowcasts_hmc"]["gpu_s"]
+        # the everyday size (docs/vignettes/getting-started.jl:266-268, 543): a few hundred points,
+        # 24 particles, 100 scenarios — lockstep against the unchanged per-scenario tasks
+        nv = 208
+        wv = make_workload("C2", n=nv, P=24, D=100)
+        datav = nc.create_transformed_data(dates[:nv], wv.y, transformation=float)
+        mv = nc.make_and_fit_model(datav, engine=eng, seed=12, n_particles=24, smc_data_proportion=0.25,
+                                   n_mcmc=2, n_hmc=2)
+        scv = nc.create_nowcast_data([row for row in wv.y_add], dates[nv:nv + 1])
+        fdv = dates[nv + 1:nv + 1 + m]
+        ev = dict(n_hmc=2, hmc_config=dict(autogp.DEFAULT_HMC))
+        nc.forecast_with_nowcasts(mv, scv[:8], fdv, 20, **ev)                       # warm both shapes
+        eng.snapshot()
+        timed("everyday_forecast_lockstep", lambda: nc.forecast_with_nowcasts(mv, scv, fdv, 20, **ev),
+              settings={**ev, "n": nv, "particles": 24, "scenarios": 100})
+        eng.ctx.combine_stats(reset=True)
+        timed("everyday_forecast_threads",
+              lambda: nc.forecast_with_nowcasts(mv, scv, fdv, 20, lockstep=False, threads=thr, **ev),
+              settings={**ev, "n": nv, "particles": 24, "scenarios": 100, "lockstep": False, "threads": thr})
+        le = legs["everyday_forecast_threads"]
+        le["combining"] = eng.ctx.combine_stats(reset=True)
+        le["over_lockstep"] = le["gpu_s"] / legs["everyday_forecast_lockstep"]["gpu_s"]
+        eng.ctx.set_combining(False)
+        timed("everyday_forecast_threads_not_combined",
+              lambda: nc.forecast_with_nowcasts(mv, scv, fdv, 20, lockstep=False, threads=thr, **ev),
+              settings={**ev, "n": nv, "particles": 24, "scenarios": 100, "lockstep": False, "threads": thr,
+                        "combining": False})
+        eng.ctx.set_combining(True)
     # ---- one fit at a vignette-scale sampler budget (reference docs/vignettes/getting-started.jl:266-268:
     #      24 particles, n_mcmc 50-200, n_hmc 20-50 on a weekly series of a few hundred points) ----
     if not args.no_vignette_fit:
@@ -326,8 +368,8 @@ def fit_forecast_wallclock(w, device, rank, args):
         res["cpu_estimate_error"] = err
         return res
     for name, leg in legs.items():
-        fan_out = name.startswith("forecast_with_nowcasts")
-        pv = 24 if name == "vignette_scale_fit" else P
+        fan_out = name.startswith("forecast_with_nowcasts") or name.startswith("everyday_forecast")
+        pv = 24 if name == "vignette_scale_fit" or name.startswith("everyday_forecast") else P
         leg["cpu_estimate"] = cpu_estimate(
             raws[name], prices, cores, pv * D if fan_out else pv,
             "one task per scenario x threads over particles (src/forecasting.jl:131-132)" if fan_out
@@ -417,6 +459,10 @@ def main():
                     help="skip the end-to-end make_and_fit_model + forecast_with_nowcasts timing")
     ap.add_argument("--no-vignette-fit", action="store_true")
     ap.add_argument("--no-mid-fit", action="store_true")
+    ap.add_argument("--no-threads-leg", action="store_true",
+                    help="skip the per-scenario-task legs (forecast_with_nowcasts as the reference runs it)")
+    ap.add_argument("--scenario-threads", type=int, default=16,
+                    help="host threads of the per-scenario-task legs (the box grants 16 cores)")
     ap.add_argument("--mid-budget", default="5,5",
                     help="n_mcmc,n_hmc of the mid-budget headline fit (default leapfrogs)")
     ap.add_argument("--hmc-leapfrog", type=int, default=3,
