@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense fp64 matrix (not in the local guide)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PMC_DIRS = [os.path.join(ROOT, "profiles", r) for r in ("r03", "r02")]   # newest first
+PMC_DIRS = [os.path.join(ROOT, "profiles", r) for r in ("r04", "r03", "r02")]   # newest first
 
 
 def F_logml(n):
@@ -113,6 +113,7 @@ def cpu_baseline(config, rank, args, idx, gpu_logml):
             cmd += [flag, str(v)]
     if args.mode == "grad":
         cmd.append("--with-grad")
+    cmd += ["--ensemble", args.ensemble]
     t0 = time.perf_counter()
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     if out.returncode != 0:
@@ -413,7 +414,14 @@ def other_configs(args):
     legs = {"C5_mixed": ["--config", "C5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                          "--no-fit"],
             "C4_one_rank_share": ["--config", "C4", "--particles", "32", "--steps", "1", "--warmup",
-                                  "1", "--headline-only"]}
+                                  "1", "--headline-only"],
+            # the HMC leapfrog over the headline items (what fit time is made of,
+            # src/make_and_fit_model.jl:91, src/forecasting.jl:65,148), on the prior ensemble (half
+            # the trees stationary: Toeplitz leaf) and on a fitted one (every tree general)
+            "C3_grad_prior": ["--mode", "grad", "--steps", "2", "--warmup", "1", "--headline-only"],
+            "C3_grad_fitted": ["--mode", "grad", "--ensemble", "fitted", "--steps", "2", "--warmup", "1",
+                               "--headline-only"],
+            "C2": ["--config", "C2", "--steps", "20", "--warmup", "3", "--headline-only"]}
     for name, extra in legs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1"] + extra
         t0 = time.perf_counter()
@@ -432,6 +440,13 @@ def other_configs(args):
              "roofline_frac": d["roofline"]["frac"], "roofline_achieved": d["roofline"]["achieved"],
              "roofline_peak": d["roofline"]["peak"], "kernels_ms_per_step": d["kernels_ms_per_step"],
              "failed_items": d["failed_items"], "wall_s_with_startup": time.perf_counter() - t0}
+        if "by_kernel" in d["roofline"]:
+            c["roofline_by_kernel"] = d["roofline"]["by_kernel"]
+            c["whole_path_frac"] = d["roofline"].get("whole_path_frac")
+            c["executed_frac_all_kernels"] = d["roofline"].get("executed_frac_all_kernels")
+        c["roofline_traffic"] = d["roofline"].get("traffic")
+        c["roofline_traffic_source"] = d["roofline"].get("traffic_source")
+        c["roofline_algorithmic_bytes_per_launch"] = d["roofline"].get("algorithmic_bytes_per_launch")
         if "mixed_precision" in d:
             mp_ = d["mixed_precision"]
             c.update(fp64_path_ms_per_step=mp_["fp64_path_ms_per_step"],
@@ -441,6 +456,53 @@ def other_configs(args):
                      frac_of_blended_peak=d["roofline"].get("frac_of_blended_peak"))
         out[name] = c
     return out
+
+
+def build_c4_step(ctx, args, world):
+    """BASELINE config C4 (n = 2048, ONE model of 256 particles x 200 scenarios, its particles
+    sharded over the ranks): a step is the PRODUCT's forecast_with_nowcasts in
+    the HMC refinement mode (reference src/forecasting.jl:131-159 with n_hmc > 0) — add_data! for all
+    scenarios from the resident factor, ONE [P_local, D] log-weight all-gather, resampling of every
+    scenario (ess_threshold = 1) with ONE descriptor exchange, then the lockstep HMC move
+    (leapfrog + 1 gradient calls of P_local x D items) and the P_local x D predictive call, the
+    mixture all-gather and the draws.  Total work is fixed: strong scaling."""
+    import datetime as dt
+
+    from nowcastautogp_amd import autogp, distributed, gp
+    from nowcastautogp_amd import nowcast as nc
+    from nowcastautogp_amd.synthetic import make_workload
+    w = make_workload("C4", n=args.n if args.config == "C4" else None,
+                      P=args.particles if args.config == "C4" else None,
+                      D=args.scenarios if args.config == "C4" else None)
+    P_total = len(w.programs)
+    # particle order: dealt round-robin by tree size, so the block partition is balanced
+    deal = distributed.deal_round_robin([len(p[0]) for p in w.programs], world)
+    order = np.concatenate(deal)
+    D, n, d, m = w.y_add.shape[0], w.n, w.t_add.size, w.t_new.size
+    dates = [dt.date(2000, 1, 2) + dt.timedelta(weeks=i) for i in range(n + d + m)]
+    eng = autogp.HipEngine.__new__(autogp.HipEngine)
+    eng.ctx = ctx
+    model = autogp.GPModel(dates[:n], w.y, n_particles=P_total, engine=eng, seed=5)
+    sl = distributed.shard(P_total)
+    mine = order[sl]
+    model.particles = [autogp.Particle(gp.from_program(w.programs[i][0], w.programs[i][1]),
+                                       float(w.programs[i][2])) for i in mine]
+    model.n_obs = n
+    tm_, ym_ = model._obs()
+    lm0, info0 = eng.logml(model.programs(), tm_, ym_)
+    assert not info0.any()
+    model._logml, model.log_weights = lm0, np.zeros(len(mine))
+    scen = nc.create_nowcast_data([row for row in w.y_add], dates[n:n + d])
+    fdates = dates[n + d:]
+    hmc = {"n_leapfrog": args.hmc_leapfrog, "eps": 0.01}
+
+    def step():
+        fc = nc.forecast_with_nowcasts(model, scen, fdates, 20, n_hmc=1, ess_threshold=1.0,
+                                       hmc_config=hmc)
+        return {"info": np.zeros(1, dtype=np.int32), "fc": fc}, None
+
+    return dict(w=w, step=step, P=len(mine), P_total=P_total, D=D, n=n, d=d, m=m, mine=mine,
+                evals_per_item=hmc["n_leapfrog"] + 2)   # leapfrog + 1 gradient evaluations + 1 predict
 
 
 def main():
@@ -459,6 +521,8 @@ def main():
                     help="skip the end-to-end make_and_fit_model + forecast_with_nowcasts timing")
     ap.add_argument("--no-vignette-fit", action="store_true")
     ap.add_argument("--no-mid-fit", action="store_true")
+    ap.add_argument("--no-c4-strong", action="store_true",
+                    help="N > 1, default config: skip the strong-scaled C4 step after the timed region")
     ap.add_argument("--no-threads-leg", action="store_true",
                     help="skip the per-scenario-task legs (forecast_with_nowcasts as the reference runs it)")
     ap.add_argument("--scenario-threads", type=int, default=16,
@@ -471,6 +535,10 @@ def main():
                     help="skip the compact C5 / C4-share legs of the default run")
     ap.add_argument("--mode", default="predict", choices=["predict", "grad"],
                     help="grad: a step is one logml + gradient call over the items (HMC leapfrog)")
+    ap.add_argument("--ensemble", default="prior", choices=["prior", "fitted"],
+                    help="prior: trees as the grammar prior draws them (about half stationary); fitted: "
+                         "every tree carries a Linear or ChangePoint node, as the particles of a model "
+                         "fitted to a trending series do (synthetic.make_ensemble)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="items in the CPU sample (0: auto)")
     ap.add_argument("--no-structured-storage", action="store_true",
                     help="store every covariance tile (ngp_set_structured_storage off): same results, for A/B timing")
@@ -522,48 +590,12 @@ def main():
     job = ka = None
     evals_per_item = 1
     if sharded:
-        # ONE model of 256 particles for the whole job, its particles sharded over the ranks
-        # (SURVEY.md section 8e).  A step is the PRODUCT's forecast_with_nowcasts in the HMC
-        # refinement mode (reference src/forecasting.jl:131-159 with n_hmc > 0): add_data! for
-        # all scenarios from the resident factor, ONE [P_local, D] log-weight all-gather,
-        # resampling of every scenario (ess_threshold = 1) with ONE descriptor exchange, then the
-        # lockstep HMC move (leapfrog + 1 gradient calls of P_local x D items) and the
-        # P_local x D predictive call, the mixture all-gather and the draws.
-        import datetime as dt
-
-        from nowcastautogp_amd import autogp, gp
-        from nowcastautogp_amd import nowcast as nc
-        w = make_workload("C4", n=args.n, P=args.particles, D=args.scenarios)
-        P_total = len(w.programs)
-        # particle order: dealt round-robin by tree size, so the block partition is balanced
-        deal = distributed.deal_round_robin([len(p[0]) for p in w.programs], world)
-        order = np.concatenate(deal)
-        D, n, d, m = w.y_add.shape[0], w.n, w.t_add.size, w.t_new.size
-        dates = [dt.date(2000, 1, 2) + dt.timedelta(weeks=i) for i in range(n + d + m)]
-        eng = autogp.HipEngine.__new__(autogp.HipEngine)
-        eng.ctx = ctx
-        model = autogp.GPModel(dates[:n], w.y, n_particles=P_total, engine=eng, seed=5)
-        sl = distributed.shard(P_total)
-        mine = order[sl]
-        model.particles = [autogp.Particle(gp.from_program(w.programs[i][0], w.programs[i][1]),
-                                           float(w.programs[i][2])) for i in mine]
-        model.n_obs = n
-        tm_, ym_ = model._obs()
-        lm0, info0 = eng.logml(model.programs(), tm_, ym_)
-        assert not info0.any()
-        model._logml, model.log_weights = lm0, np.zeros(len(mine))
-        scen = nc.create_nowcast_data([row for row in w.y_add], dates[n:n + d])
-        fdates = dates[n + d:]
-        hmc = {"n_leapfrog": args.hmc_leapfrog, "eps": 0.01}
-        P = len(mine)
-        evals_per_item = hmc["n_leapfrog"] + 2     # leapfrog + 1 gradient evaluations + 1 predict
-
-        def step():
-            fc = nc.forecast_with_nowcasts(model, scen, fdates, 20, n_hmc=1, ess_threshold=1.0,
-                                           hmc_config=hmc)
-            return {"info": np.zeros(1, dtype=np.int32), "fc": fc}, None
+        c4 = build_c4_step(ctx, args, world)
+        w, step, P, P_total, D, n, d, m = (c4[k] for k in ("w", "step", "P", "P_total", "D", "n", "d", "m"))
+        mine, evals_per_item = c4["mine"], c4["evals_per_item"]
     else:
-        w, progs, Y, tt = bench_items(args.config, rank, args.n, args.particles, args.scenarios)
+        w, progs, Y, tt = bench_items(args.config, rank, args.n, args.particles, args.scenarios,
+                                      ensemble=args.ensemble)
         P, D, n, d, m = len(w.programs), w.y_add.shape[0], w.n, w.t_add.size, w.t_new.size
         P_total = P
         if grad_mode:
@@ -613,6 +645,34 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     bad = int((out["info"] != 0).sum())
+
+    # N > 1 on the default line: the C3 figure above is weak scaling of replicas (x N by
+    # construction).  The number north_star's ">= 6x at 8 GPUs" is about is the STRONG-scaled
+    # C4 step (256 particles x 200 scenarios sharded over the ranks, one all-gather per weight
+    # update): run it here too, after the timed region, so a default scaling run records it.
+    c4_strong = None
+    if world > 1 and args.config == "C3" and not grad_mode and not args.no_c4_strong:
+        if job is not None:
+            job.close()
+            job = None
+        c4 = build_c4_step(ctx, args, world)
+        c4["step"]()                                   # warm-up
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        c4["step"]()
+        torch.cuda.synchronize()
+        dist.barrier()
+        tc = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        evals = c4["P_total"] * c4["D"] * c4["evals_per_item"]
+        c4_strong = {"ms_per_step": float(tc.item()) * 1e3, "value": evals / float(tc.item()),
+                     "unit": "particle-logml/s", "scaling": "strong", "steps": 1,
+                     "particles_total": c4["P_total"], "particles_per_gpu": c4["P"], "scenarios": c4["D"],
+                     "collectives_per_step": "1 log-weight all-gather [P_local, D] + 1 descriptor "
+                                             "exchange + 1 mixture all-gather (independent of D)",
+                     "what": "BASELINE configs[3] through the product's forecast_with_nowcasts(n_hmc=1, "
+                             "ess_threshold=1): max over ranks of one step between barriers"}
 
     if args.headline_only:
         args.no_fit = args.no_cpu_baseline = args.no_other_configs = True
@@ -685,17 +745,26 @@ def main():
         col = prof.get(dom_key, zero)
         thin = prof.get("chol_col_thin", zero)      # chol_col_kernel: thin / full steps
         ach = col["flops"] / (col["ms"] * 1e-3) * 1e-12 if col["ms"] else 0.0
-        fat = prof.get("chol_col_mixed" if mixed else "chol_col", zero)
+        fat = prof.get("chol_col_mixed" if mixed else ("chol_col_grad" if dom_key == "chol_col_grad" else "chol_col"), zero)
         both_ms = fat["ms"] + thin["ms"]
         ach_both = (fat["flops"] + thin["flops"]) / (both_ms * 1e-3) * 1e-12 if both_ms else 0.0
         peak = FP32_MFMA_PEAK_TFLOPS if mixed else FP64_MFMA_PEAK_TFLOPS
-        kern_key = KERNEL_OF_CLASS.get("chol_col_grad" if (grad_mode and dom_key == "chol_col")
-                                       else dom_key, dom_key)
+        kern_key = KERNEL_OF_CLASS.get(dom_key, dom_key)
         npts = n + d if not grad_mode else n + d
         nb = (npts + 63) // 64 if grad_mode else npts // 64      # gradient jobs pad to a block
         fat_steps = nb // 2                                 # fat launches one item goes through
-        per_launch = B * fat_steps * args.steps / max(col["launches"], 1)
-        pmc_name = args.config + ("_grad" if grad_mode else "")
+        # items behind every launch of a class: a gradient job runs its stationary trees (regular
+        # series, >= 256 items: the library's routing) as a Toeplitz leaf on the value kernels
+        # (class chol_col) and the rest as the general leaf (chol_col_grad, grad_kinv)
+        items_of = {}
+        if grad_mode:
+            n_toep = 0 if args.no_structured_storage else sum(
+                1 for p_ in progs if len(p_[0]) <= 31 and not any(int(o) in (2, 8) for o in p_[0]))
+            items_of = {"chol_col": n_toep, "chol_col_grad": B - n_toep, "grad_kinv": B - n_toep}
+        b_dom = items_of.get(dom_key, B)
+        per_launch = b_dom * (fat_steps if dom_key.startswith("chol_col") else 1) * args.steps \
+            / max(col["launches"], 1)
+        pmc_name = args.config + ("_grad" if grad_mode else "") + ("_fitted" if args.ensemble == "fitted" else "")
         traffic, traffic_src = measured_traffic(pmc_name, kern_key, per_launch)
         names = {"C1": "C1", "C2": "C2", "C3": "C3", "C4": "C4", "C5": "C5"}[args.config]
         F_item = F_logml_grad(npts) if grad_mode else F_logml(npts)
@@ -708,9 +777,10 @@ def main():
                       ("chol_col_glds_kernel (the fat steps of the column sweep: "
                        "v_mfma_f64_4x4x4_4b_f64 trailing update of two block columns from "
                        "LDS-DMA staged operands, in-register 64-wide triangular solve"
-                       + ("; in a gradient job the aux block is [I ; y'], so the sweep also "
-                          "produces W = L^-T, block upper triangular)" if grad_mode or sharded
-                          else ")")) if dom_key == "chol_col" else kern_key,
+                       + ("; the gradient-geometry instantiation: the aux block is [I ; y'], so the "
+                          "sweep also produces W = L^-T, block upper triangular)"
+                          if dom_key == "chol_col_grad" else ")")) if dom_key in ("chol_col", "chol_col_grad")
+                      else kern_key,
             "timing_class": dom_key,
             "achieved": ach,
             "peak": peak,
@@ -744,12 +814,25 @@ def main():
             roof["executed_tflops_all_kernels"] = ex / (total_ms * 1e-3) * 1e-12 if total_ms else 0.0
             roof["executed_frac_all_kernels"] = roof["executed_tflops_all_kernels"] / peak
         if grad_mode:
-            kv = prof.get("grad_kinv", zero)
-            roof["grad_kinv"] = {
-                "kernel": KERNEL_OF_CLASS["grad_kinv"],
-                "achieved": kv["flops"] / (kv["ms"] * 1e-3) * 1e-12 if kv["ms"] else 0.0,
-                "frac": (kv["flops"] / (kv["ms"] * 1e-3) * 1e-12 / peak) if kv["ms"] else 0.0,
-                "avg_launch_ms": kv["ms"] / max(kv["launches"], 1), "launches": kv["launches"]}
+            # one entry per MFMA kernel of the call, each with ITS flops, algorithmic bytes, launches
+            # and measured HBM bytes (never pooled over instantiations)
+            roof["by_kernel"] = {}
+            for cls in ("chol_col_grad", "chol_col", "grad_kinv"):
+                kv = prof.get(cls, zero)
+                if not kv["launches"]:
+                    continue
+                nl = b_cls = items_of.get(cls, B)
+                per = b_cls * (fat_steps if cls.startswith("chol_col") else 1) * args.steps / kv["launches"]
+                tr, _ = measured_traffic(pmc_name, KERNEL_OF_CLASS[cls], per)
+                a = kv["flops"] / (kv["ms"] * 1e-3) * 1e-12 if kv["ms"] else 0.0
+                roof["by_kernel"][cls] = {
+                    "kernel": KERNEL_OF_CLASS[cls], "items": nl, "achieved": a, "frac": a / peak,
+                    "launches": kv["launches"], "avg_launch_ms": kv["ms"] / kv["launches"],
+                    "ms_per_step": kv["ms"] / args.steps,
+                    "algorithmic_flops_per_launch": kv["flops"] / kv["launches"],
+                    "algorithmic_bytes_per_launch": kv["bytes"] / kv["launches"],
+                    "traffic": tr["bytes_per_launch"] if tr else None}
+            roof["grad_kinv"] = roof["by_kernel"].get("grad_kinv")
         if mixed:
             f32 = float(np.mean(mixed_stats["frac_f32"]))
             roof["peak_basis"] = ("dense fp32 MFMA (v_mfma_f32_32x32x2_f32), the guide's 'Peak FP32 "
@@ -788,7 +871,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak",
+            "scaling": "strong" if sharded else ("weak (replicas)" if world > 1 else "weak"),
             "vs_baseline": None,
             "dtype": ("f32 matrix cores for tile products below the error threshold + f64 "
                       "(accumulators, factor, solves, Gram refinement)") if mixed else "f64",
@@ -801,6 +884,9 @@ def main():
                                        f"{evals_per_item - 2} leapfrog(s)) per step: lockstep calls of "
                                        f"{B} items per GPU" if sharded else
                                        "every item its own kernel parameters (no dedupe)")
+                                    + ("; ensemble 'fitted': every tree carries a Linear or ChangePoint "
+                                       "node (no stationary tree: what a fit of a trending series ends with)"
+                                       if args.ensemble == "fitted" else "")
                                     + ("; step = ONE run of a resident logml + gradient job "
                                        "(ngp_grad_stage: trees, dates, observations staged before the timed "
                                        "region; per step the parameters go up and the results come back)"
@@ -834,6 +920,8 @@ def main():
                 "ms_per_forecast_factor_resident": cached_ms,
                 "reference_equivalent_evals_per_s": 2 * B / (shared_ms * 1e-3),
             }
+        if c4_strong is not None:
+            res["c4_strong"] = c4_strong
         if fit_res is not None:
             res["fit_forecast"] = fit_res
         if not args.no_cpu_baseline:

@@ -229,6 +229,12 @@ ngp_status ngp_grad_stage(ngp_ctx *ctx, int32_t B, const ngp_kernel *kernels, in
                           const double *t, const double *y, int64_t ldy, ngp_grad_job **out);
 ngp_status ngp_grad_job_set_params(ngp_grad_job *job, const double *params, const double *noise);
 ngp_status ngp_grad_job_run(ngp_grad_job *job, double *logml, double *grad, int32_t *info);
+/* How the job is carried (diagnostic; tests use it to pick the first and last item of every chunk):
+ * out5 = { items of the general leaf, items per memory-driven chunk of its last run (0 before the
+ * first), items of the Toeplitz leaf (stationary trees on a regular series, ngp_set_structured_storage),
+ * items per chunk of its last run, 1 if the two leaves run side by side }.  Leaf items keep the
+ * caller's order.                                                                                */
+ngp_status ngp_grad_job_info(const ngp_grad_job *job, int32_t *out5);
 void       ngp_grad_job_destroy(ngp_grad_job *job);
 
 /* ---- particle weights -----------------------------------------------------
@@ -380,8 +386,11 @@ void       ngp_factor_destroy(ngp_factor *f);
  * 8 = diag_ahead_kernel (side stream, overlaps classes 1 and 6), 9 = the
  * mixed-precision fat steps (chol_col_glds_kernel<MIXED>), 10 = Gram refinement
  * of NGP_PREC_MIXED (backward sweep, covariance apply, small products), 11 = the
- * reverse-mode contraction of a gradient job (grad_alpha / grad_contract* / grad_reduce). */
-#define NGP_NUM_KERNEL_CLASSES 12
+ * reverse-mode contraction of a gradient job (grad_alpha / grad_contract* / grad_reduce),
+ * 12 = the fat steps of a gradient job's general leaf (chol_col_glds_kernel<.., IDENT>: aux
+ * rows [I ; y'], the sweep that also produces W = L^-T) — a different instantiation from class 0,
+ * with its own flops, bytes and rate (the Toeplitz leaf of a gradient job runs class 0). */
+#define NGP_NUM_KERNEL_CLASSES 13
 typedef struct ngp_profile {
     double   ms[NGP_NUM_KERNEL_CLASSES];       /* summed device time per class */
     int64_t  launches[NGP_NUM_KERNEL_CLASSES]; /* kernel launches per class    */

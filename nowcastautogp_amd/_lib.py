@@ -20,7 +20,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NGP_LIB") or os.path.join(_HERE, "libngp.so")  # NGP_LIB: A/B builds
 
 KERNEL_CLASSES = ("chol_col", "chol_diag", "gram", "epilogue", "fill", "grad_kinv", "chol_col_thin",
-                  "aux_update", "diag_ahead", "chol_col_mixed", "refine", "grad_contract")
+                  "aux_update", "diag_ahead", "chol_col_mixed", "refine", "grad_contract",
+                  "chol_col_grad")
 
 # every symbol include/ngp.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = (
@@ -35,7 +36,7 @@ SYMBOLS = (
     "ngp_factor_destroy", "ngp_mixture_sample", "ngp_set_structured_storage", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
     "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
     "ngp_selftest_mfma_f32_layout", "ngp_set_combining", "ngp_combine_stats",
-    "ngp_weights_unpad_normalize",
+    "ngp_weights_unpad_normalize", "ngp_grad_job_info",
 )
 
 
@@ -88,6 +89,7 @@ def load():
         "ngp_grad_stage": (i32, [vp, i32, KP, i32, f64p, f64p, i64, C.POINTER(vp)]),
         "ngp_grad_job_set_params": (i32, [vp, f64p, f64p]),
         "ngp_grad_job_run": (i32, [vp, f64p, f64p, i32p]),
+        "ngp_grad_job_info": (i32, [vp, i32p]),
         "ngp_grad_job_destroy": (None, [vp]),
         "ngp_weights_normalize": (i32, [i32, f64p, f64p, f64p, f64p]),
         "ngp_weights_normalize_cols": (i32, [i32, i32, f64p, f64p, f64p, f64p]),
@@ -265,6 +267,13 @@ class GradJob:
         lm, info = np.empty(self.n), np.zeros(self.n, dtype=np.int32)
         _chk(L.ngp_grad_job_run(self._h, dptr(lm), dptr(grad), iptr(info)), "ngp_grad_job_run")
         return lm, grad, info
+
+    def info(self) -> dict:
+        """``ngp_grad_job_info``: how the batch is carried (leaves, chunk sizes of the last run)."""
+        out = np.zeros(5, dtype=np.int32)
+        _chk(load().ngp_grad_job_info(self._h, iptr(out)), "ngp_grad_job_info")
+        return dict(general_items=int(out[0]), general_chunk=int(out[1]), toeplitz_items=int(out[2]),
+                    toeplitz_chunk=int(out[3]), side_by_side=bool(out[4]))
 
     def close(self):
         if self._h:

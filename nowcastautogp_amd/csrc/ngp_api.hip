@@ -824,8 +824,10 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
             by -= lazy_frac * 8.0 * NB * (rm + (fat ? std::max(0.0, rm - NB) : 0.0));
         }
         // class 0: the LDS-DMA kernel of the fat steps (the dominant kernel, the roofline figure);
-        // class 6: the direct-load kernel of the thin / full steps
-        tm.run(fat ? (mixed ? 9 : 0) : 6, bc * fl, bc * by,
+        // class 12: its gradient-geometry instantiation (aux rows [I ; y'], <.., IDENT>: another
+        // kernel with its own flops, bytes and rate); class 6: the direct-load kernel of the thin /
+        // full steps
+        tm.run(fat ? (mixed ? 9 : (g.aux_identity ? 12 : 0)) : 6, bc * fl, bc * by,
                [&] { launch_chol_col(g, p, bc, jj, mode, k0_col, s, sp); });
         if (mixed && fat && order_buf && jj >= 8 && jj % MIXED_REORDER == 8) {
             // p0.order stays null (dispatch order) unless the ranking was really launched:
@@ -1771,6 +1773,7 @@ struct GradLeaf {
     bool fresh = false;                    // info / logdet still hold the zeros they were staged with
     bool progs_dirty = false;              // set_params since the last upload
     ngp_spec spec{};
+    int last_chunk = 0;                    // items per memory-driven chunk of the last run (ngp_grad_job_info)
 };
 
 namespace {
@@ -2102,6 +2105,7 @@ ngp_status grad_leaf_run(GradLeaf *j, double *logml, double *grad, int32_t *info
         if (!st) break;
         if (st != NGP_ERR_TOO_LARGE || r.Bc <= 1) return st;
     }
+    j->last_chunk = r.Bc;
     EventTimer tm(c->profiling, c->stream);
     ngp_status st = r.launch(lane_of(c), tm, false);
     hipError_t e = hipStreamSynchronize(c->stream);
@@ -2126,8 +2130,8 @@ ngp_status grad_pair_run(GradLeaf *a, double *lm_a, double *g_a, int32_t *info_a
     LeafRun ra, rb;
     ra.j = a;
     rb.j = b;
-    ra.Bc = a->B;
-    rb.Bc = b->B;
+    ra.Bc = a->last_chunk = a->B;
+    rb.Bc = b->last_chunk = b->B;
     WsPlan measure{c, true}, take{c, false};
     (void)ra.layout(measure);
     (void)rb.layout(measure);
@@ -2413,6 +2417,16 @@ static ngp_status grad_job_run_resident(ngp_grad_job *j, double *logml, double *
     ngp_status st = run_leaf(j->gen, j->idx_gen);
     if (!st) st = run_leaf(j->toep, j->idx_toep);
     return st;
+}
+
+extern "C" ngp_status ngp_grad_job_info(const ngp_grad_job *j, int32_t *out5) {
+    if (!j || !out5) return NGP_ERR_ARG;
+    out5[0] = j->gen ? j->gen->B : 0;
+    out5[1] = j->gen ? j->gen->last_chunk : 0;
+    out5[2] = j->toep ? j->toep->B : 0;
+    out5[3] = j->toep ? j->toep->last_chunk : 0;
+    out5[4] = j->side_by_side ? 1 : 0;
+    return NGP_OK;
 }
 
 extern "C" void ngp_grad_job_destroy(ngp_grad_job *j) {

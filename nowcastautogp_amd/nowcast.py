@@ -220,12 +220,20 @@ def forecast_with_nowcasts(base_model: GPModel, nowcasts: Sequence[TData], forec
         # works on its own clone with its own streams: the result does not depend on the schedule
         # beyond the last bits the library's batching decides.  A clone forecasts ONCE, so its
         # predictive call is the one-shot entry point (combinable), not a resident factor.
+        import sys
         from concurrent.futures import ThreadPoolExecutor
         models = [clone() for _ in nowcasts]
         for m in models:
             m._one_shot_predict = True
-        with ThreadPoolExecutor(max_workers=int(threads)) as pool:
-            results = list(pool.map(task, models, nowcasts))
+        # a task that comes back from the library needs the interpreter lock to go on; with the
+        # default 5 ms switch interval it can wait that long for a task that is between two calls
+        old = sys.getswitchinterval()
+        sys.setswitchinterval(min(old, 1e-4))
+        try:
+            with ThreadPoolExecutor(max_workers=int(threads)) as pool:
+                results = list(pool.map(task, models, nowcasts))
+        finally:
+            sys.setswitchinterval(old)
         if verbose:
             print(f"Nowcast scenarios: {len(results)}/{len(nowcasts)} ({int(threads)} threads)")
         return np.hstack(results)

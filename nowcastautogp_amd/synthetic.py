@@ -62,12 +62,25 @@ def make_series(rng: np.random.Generator, n: int, d: int, D: int):
 
 
 def make_ensemble(rng: np.random.Generator, P: int, depth_cap: int = 4,
-                  config: gp.GPConfig | None = None):
+                  config: gp.GPConfig | None = None, ensemble: str = "prior"):
+    """``ensemble``: "prior" — trees as the grammar prior draws them (the start of every fit; about
+    half of them stationary); "fitted" — what a fit of a trending series ends with (DESIGN.md
+    section 4.13: ``scripts/fit_structures.py`` finds not one stationary tree among the particles of
+    a fitted model): the same draws, but a tree without a Linear or ChangePoint node gets one —
+    alternately ``tree + Linear`` and ``ChangePoint(tree, Linear)`` — so every item takes the general
+    gradient leaf and stores every tile, as the refinement calls on a fitted model do
+    (reference src/forecasting.jl:145-148)."""
     config = config or gp.GPConfig()
     out = []
-    for _ in range(P):
+    for k in range(P):
         tree = gp.sample_tree(rng, config, depth_cap=depth_cap)
         ops, params = gp.to_program(tree)
+        if ensemble == "fitted" and not any(int(o) in (2, 8) for o in ops):
+            lin = gp.Linear(float(rng.uniform(0.2, 0.8)), float(np.exp(rng.normal(-1.5, 1.0))),
+                            float(np.exp(rng.normal(-1.5, 1.0))))
+            tree = gp.Plus(tree, lin) if k % 2 == 0 else gp.ChangePoint(
+                tree, lin, float(rng.uniform(0.3, 0.7)), float(np.exp(rng.normal(-2.5, 0.5))))
+            ops, params = gp.to_program(tree)
         noise = float(10.0 ** rng.uniform(-4.0, -1.0))
         out.append((ops, params, noise))
     return out
@@ -75,7 +88,7 @@ def make_ensemble(rng: np.random.Generator, P: int, depth_cap: int = 4,
 
 def make_workload(name: str = "C3", n: int | None = None, P: int | None = None,
                   D: int | None = None, d: int = 1, m: int = 9, depth_cap: int = 4,
-                  seed_offset: int = 0) -> Workload:
+                  seed_offset: int = 0, ensemble: str = "prior") -> Workload:
     idx, n0, P0, D0 = CONFIGS[name]
     n = n or n0
     P = P or P0
@@ -83,7 +96,7 @@ def make_workload(name: str = "C3", n: int | None = None, P: int | None = None,
     rng = np.random.Generator(np.random.PCG64(20240101 + idx + 1000 * seed_offset))
     t_all = np.arange(n + d + m, dtype=np.float64) / (n - 1)
     y, y_add, slope, intercept = make_series(rng, n, d, D)
-    programs = make_ensemble(rng, P, depth_cap)
+    programs = make_ensemble(rng, P, depth_cap, ensemble=ensemble)
     return Workload(name, n, t_all[:n].copy(), y, t_all[n:n + d].copy(), y_add,
                     t_all[n + d:].copy(), programs, slope, intercept)
 
@@ -112,12 +125,12 @@ def jitter_programs(programs, copies: int, rng: np.random.Generator, rel: float 
 
 
 def bench_items(name: str = "C3", rank: int = 0, n: int | None = None, P: int | None = None,
-                D: int | None = None):
+                D: int | None = None, ensemble: str = "prior"):
     """The (particle, scenario) items of one ``bench.py`` step on one rank: every item its own
     kernel (``jitter_programs``) over the n + d points of its scenario.  Shared by the GPU leg and
     by ``oracle/cpu_baseline.py`` so both see identical items.  Returns (workload, programs,
     Y [B, n + d], t [n + d])."""
-    w = make_workload(name, n=n, P=P, D=D, seed_offset=rank)
+    w = make_workload(name, n=n, P=P, D=D, seed_offset=rank, ensemble=ensemble)
     Pn, Dn, nn, d = len(w.programs), w.y_add.shape[0], w.n, w.t_add.size
     rng = np.random.Generator(np.random.PCG64(99 + rank))
     progs = jitter_programs(w.programs, Dn, rng) if Dn > 1 else list(w.programs)

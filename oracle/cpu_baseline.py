@@ -35,9 +35,9 @@ sys.path.insert(0, ROOT)
 _G = {}
 
 
-def _init(config, rank, n, P, D):
+def _init(config, rank, n, P, D, ensemble="prior"):
     from nowcastautogp_amd.synthetic import bench_items
-    _G["items"] = bench_items(config, rank, n, P, D)
+    _G["items"] = bench_items(config, rank, n, P, D, ensemble=ensemble)
 
 
 def _predict(i):
@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--particles", type=int, default=None)
     ap.add_argument("--scenarios", type=int, default=None)
+    ap.add_argument("--ensemble", default="prior", choices=["prior", "fitted"])
     ap.add_argument("--items", default="")
     ap.add_argument("--sizes", default="")
     ap.add_argument("--per-size", type=int, default=2)
@@ -130,7 +131,7 @@ def main():
     cores, quota = usable_cores()
     if a.workers <= 0:
         a.workers = min(cores, a.max_workers) if a.max_workers > 0 else cores
-    init = (a.config, a.rank, a.n, a.particles, a.scenarios)
+    init = (a.config, a.rank, a.n, a.particles, a.scenarios, a.ensemble)
     ctx = mp.get_context("fork")          # this process never touches a GPU
     out = {"workers": a.workers, "blas_threads_per_worker": 1, "usable_cores": cores,
            "cgroup_cpu_quota": quota, "host_cores": os.cpu_count()}

@@ -1,6 +1,6 @@
 """The command the PMC passes profile: one HBM microbenchmark of known size (calibrates the
 FETCH_SIZE / WRITE_SIZE units on this box) followed by headline steps of bench.py's workload.
-Usage (under rocprofv3): python3 scripts/pmc_workload.py C3 [particles] [predict|grad] [scenarios]
+Usage (under rocprofv3): python3 scripts/pmc_workload.py C3 [particles] [predict|grad] [scenarios] [prior|fitted]
 (grad: one logml + gradient call over the same items, bench.py --mode grad; scenarios: fewer copies
 of EVERY particle instead of fewer particles — with structured storage the traffic of an item
 depends on its tree, so the profiled batch must keep the ensemble's mix)"""
@@ -22,9 +22,10 @@ config = sys.argv[1] if len(sys.argv) > 1 else "C3"
 P = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] not in ("", "-") else None
 mode = sys.argv[3] if len(sys.argv) > 3 else "predict"
 D = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] not in ("", "-") else None
+ensemble = sys.argv[5] if len(sys.argv) > 5 else "prior"
 ctx = _lib.Context(0)
 ctx.microbench_hbm(1 << 30)          # stream_write_kernel 2 x 1 GiB, stream_copy_kernel 2 x (1 + 1) GiB
-w, progs, Y, tt = bench_items(config, 0, None, P, D)
+w, progs, Y, tt = bench_items(config, 0, None, P, D, ensemble=ensemble)
 if mode == "grad":
     lm, g, info = ctx.logml_grad_batch(progs, tt, Y)
     print("items", len(progs), "failed", int(np.count_nonzero(info)))

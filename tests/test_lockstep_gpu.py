@@ -204,3 +204,79 @@ def test_c_abi_collective_at_world_size_one(eng):
     with pytest.raises(_lib.NgpError):
         comm.allgather_normalize(lw, 0)
     comm.close()
+
+
+def _is_stationary(prog):
+    """the library's routing rule for gradient jobs (include/ngp.h ngp_set_structured_storage):
+    no Linear / ChangePoint node, at most 16 leaves"""
+    return len(prog[0]) <= 31 and not any(int(o) in (2, 8) for o in prog[0])
+
+
+def _check_gradient_batch(eng, progs, tt, Y, tag, expect_pair=False):
+    """stage -> run once -> oracle parity on the first and last item of every memory-driven chunk
+    of every leaf + 12 spread items; finite and status 0 on ALL items"""
+    from nowcastautogp_amd._abi import KernelArray
+    B = len(progs)
+    ka = KernelArray(progs)
+    job = eng.ctx.stage_grad(ka, tt, Y)
+    lm, g, info = job.run()
+    lay = job.info()
+    job.close()
+    assert not info.any() and np.isfinite(lm).all() and np.isfinite(g).all()
+    assert lay["side_by_side"] == expect_pair
+    stat = np.array([_is_stationary(p) for p in progs])
+    leaves = []
+    if lay["toeplitz_items"]:
+        leaves.append((np.flatnonzero(stat), lay["toeplitz_chunk"]))
+        assert lay["toeplitz_items"] == int(stat.sum())
+    gen_idx = np.flatnonzero(~stat) if lay["toeplitz_items"] else np.arange(B)
+    assert lay["general_items"] == gen_idx.size
+    if gen_idx.size:
+        leaves.append((gen_idx, lay["general_chunk"]))
+    picks = {int(v) for v in np.linspace(0, B - 1, 12)}
+    nchunks = []
+    for idx, chunk in leaves:
+        assert chunk > 0
+        starts = list(range(0, idx.size, chunk))
+        nchunks.append(len(starts))
+        for s0 in starts:
+            picks |= {int(idx[s0]), int(idx[min(s0 + chunk, idx.size) - 1])}
+    off = np.concatenate([[0], np.cumsum(ka._npar + 1)])
+    worst = 0.0
+    for i in sorted(picks):
+        ev = np.linalg.eigvalsh(oracle_np.cov(progs[i], tt, tt, True))     # symmetric: cond = ratio
+        cond = float(ev[-1] / ev[0])
+        rlm, rg, ri = oracle_np.logml_grad(progs[i], tt, Y[i] if Y.ndim == 2 else Y)
+        assert ri == 0
+        check(f"{tag}:logml", lm[i], rlm, TOL_LOGML, cond, ctx=i)
+        check(f"{tag}:gradient", g[off[i]:off[i + 1]], rg, 1e-7, cond, ctx=(i, bool(stat[i])))
+        worst = max(worst, nerr(g[off[i]:off[i + 1]], rg))
+    print(f"{tag}: {B} items, layout {lay}, chunks per leaf {nchunks}, {len(picks)} items against "
+          f"the oracle, worst gradient error {worst:.2e}")
+    return lay, nchunks
+
+
+@pytest.mark.parametrize("ensemble", ["prior", "fitted"])
+def test_headline_c3_gradient_batch_against_the_oracle(eng, ensemble):
+    """BASELINE.json configs[2] as ``bench.py --mode grad`` runs it: the 12,800 (particle, scenario)
+    items as ONE resident gradient job — both leaves on the prior ensemble (stationary trees on the
+    Toeplitz path, the others general), every memory-driven chunk — run once; and the same on the
+    'fitted' ensemble (no stationary tree: what ``mcmc_parameters!`` on a fitted model evaluates,
+    reference src/forecasting.jl:145-148).  Stated tolerances: logml 1e-10, gradient 1e-7 normwise
+    per item, both condition-aware and recorded (tests/util.check)."""
+    w, progs, Y, tt = bench_items("C3", 0, ensemble=ensemble)
+    assert len(progs) == 12800 and tt.size == 2049
+    lay, nchunks = _check_gradient_batch(eng, progs, tt, Y, f"test_headline_c3_gradient_batch[{ensemble}]")
+    if ensemble == "prior":
+        assert lay["toeplitz_items"] > 0 and lay["general_items"] > 0
+    else:
+        assert lay["toeplitz_items"] == 0 and lay["general_items"] == 12800
+    assert max(nchunks) >= 2          # the general leaf does not fit the device in one piece
+
+
+def test_mixed_batch_of_160_items_runs_its_leaves_side_by_side_against_the_oracle(eng):
+    """128-255 mixed items of a long series: the two leaves run side by side on two stream pairs
+    (grad_pair_run) — checked against the oracle itself, not only against the general path."""
+    w, progs, Y, tt = bench_items("C3", 0, P=32, D=5)
+    assert len(progs) == 160
+    _check_gradient_batch(eng, progs, tt, Y, "test_mixed_batch_160_side_by_side", expect_pair=True)
