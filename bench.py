@@ -88,11 +88,12 @@ def measured_traffic(config, kernel_key, items_per_launch):
         return None, path
     # the profiled job may cover fewer items per launch than this run's launches do (the PMC passes
     # serialise the GPU, so they use a smaller batch): HBM bytes scale with the items of a launch
-    scale = (items_per_launch / d["items"]) if d.get("items") else 1.0
+    prof_items = (d.get("items_by_kernel") or {}).get(kernel_key) or d.get("items")
+    scale = (items_per_launch / prof_items) if prof_items else 1.0
     rd, wr = k["read_bytes_per_launch"] * scale, k["written_bytes_per_launch"] * scale
     return {"bytes_per_launch": rd + wr, "read_bytes_per_launch": rd,
             "written_bytes_per_launch": wr,
-            "scaled_from_items_per_launch": d.get("items"), "to_items_per_launch": items_per_launch,
+            "scaled_from_items_per_launch": prof_items, "to_items_per_launch": items_per_launch,
             "launches_profiled": k["launches"], "workload_profiled": d.get("workload"),
             "commit": d.get("commit")}, os.path.relpath(path, ROOT)
 

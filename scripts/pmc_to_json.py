@@ -46,8 +46,18 @@ except Exception:
     commit = None
 import re
 m = re.search(r"items (\d+)", workload)
+mg, mt = re.search(r"general_items (\d+)", workload), re.search(r"toeplitz_items (\d+)", workload)
+items_by_kernel = {}
+if mg and mt:   # a gradient job: its two leaves run different kernels over different items
+    ng, nt = int(mg.group(1)), int(mt.group(1))
+    for k in kernels:
+        if k.startswith("chol_col") and ", true" in k or k.startswith("grad_kinv") or k.startswith("grad_alpha"):
+            items_by_kernel[k] = ng
+        elif k.startswith("chol_col") or k.startswith("aux_back") or k.startswith("toep_"):
+            items_by_kernel[k] = nt if nt else ng
 out = {"config": config, "workload": workload, "commit": commit,
        "items": int(m.group(1)) if m else None,   # items every launch of the profiled job covered
+       "items_by_kernel": items_by_kernel,        # ... per kernel where the leaves differ
        "calibration": {"kernel": "stream_copy_kernel, 2^30 B read + 2^30 B written per launch",
                        "bytes_per_FETCH_SIZE_unit": cal_r, "bytes_per_WRITE_SIZE_unit": cal_w,
                        "guide_expectation": "2048 (1 KiB x 2, gfx950 halving) and 1024"},

@@ -27,8 +27,15 @@ ctx = _lib.Context(0)
 ctx.microbench_hbm(1 << 30)          # stream_write_kernel 2 x 1 GiB, stream_copy_kernel 2 x (1 + 1) GiB
 w, progs, Y, tt = bench_items(config, 0, None, P, D, ensemble=ensemble)
 if mode == "grad":
-    lm, g, info = ctx.logml_grad_batch(progs, tt, Y)
-    print("items", len(progs), "failed", int(np.count_nonzero(info)))
+    from nowcastautogp_amd._abi import KernelArray
+    job = ctx.stage_grad(KernelArray(progs), tt, Y)
+    lm, g, info = job.run()
+    lay = job.info()
+    job.close()
+    # the two leaves of a gradient job run different kernels over different items: the counters of a
+    # kernel are per launch over ITS leaf's items (pmc_to_json.py records them per kernel)
+    print("items", len(progs), "failed", int(np.count_nonzero(info)),
+          "general_items", lay["general_items"], "toeplitz_items", lay["toeplitz_items"])
 else:
     if config == "C5":
         ctx.set_spec(default_spec(NGP_PREC_MIXED))
