@@ -151,6 +151,19 @@ ngp_status  ngp_kernel_check(const ngp_kernel *k);
  * ngp_combine_stats: out4 = { requests seen, launch sequences run for them, largest group,
  * requests that shared a sequence with at least one other }; reset != 0 clears the counters.  */
 ngp_status ngp_set_combining(ngp_ctx *ctx, int32_t on);
+/* Batch-invariant arithmetic (off by default; applies to jobs staged after the call).  By default
+ * a few decisions follow the size of the batch an item travels in, for speed: late block columns of
+ * a small chunk are split along k, a small mixed gradient batch runs all its items on the general
+ * leaf while a large one gives its stationary trees to the Toeplitz leaf, the contraction of a small
+ * batch cuts its tiles finer and picks one kernel shape for all its trees, a single-chunk job's
+ * epilogue reads resident tables.  Each of these changes a summation order or an arithmetic path:
+ * results agree to rounding (1e-13 on logml, 1e-11 on gradients in the tests) but not bit for bit, so
+ * what a caller gets depends on who shared its launch sequence — with combining, on thread timing.
+ * With this option on, every such decision is taken from the item and the series alone: an item's
+ * outputs are the same bits whether it is evaluated alone, in a lockstep P x D call or in a
+ * combined group (tests/test_combine_gpu.py, tests/test_lockstep_gpu.py), at the price of the
+ * small-batch shortcuts (64 items at n = 2048: see DESIGN.md section 4.14).                    */
+ngp_status ngp_set_batch_invariant(ngp_ctx *ctx, int32_t on);
 ngp_status ngp_combine_stats(ngp_ctx *ctx, int64_t *out4, int32_t reset);
 
 /* ---- covariance assembly (diagnostic / small blocks) ---------------------

@@ -114,6 +114,10 @@ default; `set_combining(ctx, false)` makes every call wait for the context and r
 """
 set_combining(c::Context, on::Bool) =
     check(ccall((:ngp_set_combining, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on), "ngp_set_combining")
+"an item's outputs no longer depend, in their last bits, on the batch it travels in (include/ngp.h)"
+set_batch_invariant(c::Context, on::Bool) =
+    check(ccall((:ngp_set_batch_invariant, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on),
+          "ngp_set_batch_invariant")
 function combine_stats(c::Context; reset::Bool = false)
     out = zeros(Int64, 4)
     check(ccall((:ngp_combine_stats, LIBNGP), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int32), c.h, out, reset),

@@ -36,7 +36,7 @@ SYMBOLS = (
     "ngp_factor_destroy", "ngp_mixture_sample", "ngp_set_structured_storage", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
     "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
     "ngp_selftest_mfma_f32_layout", "ngp_set_combining", "ngp_combine_stats",
-    "ngp_weights_unpad_normalize", "ngp_grad_job_info",
+    "ngp_weights_unpad_normalize", "ngp_grad_job_info", "ngp_set_batch_invariant",
 )
 
 
@@ -119,6 +119,7 @@ def load():
                                      i32p, i32p]),
         "ngp_set_structured_storage": (i32, [vp, i32]),
         "ngp_set_combining": (i32, [vp, i32]),
+        "ngp_set_batch_invariant": (i32, [vp, i32]),
         "ngp_combine_stats": (i32, [vp, C.POINTER(C.c_int64), i32]),
         "ngp_profile_enable": (i32, [vp, i32]),
         "ngp_profile_reset": (i32, [vp]),
@@ -584,6 +585,11 @@ class Context:
         """Combining of concurrent one-shot callers (include/ngp.h "concurrent callers"); on by
         default."""
         _chk(load().ngp_set_combining(self._h, 1 if on else 0), "ngp_set_combining")
+
+    def set_batch_invariant(self, on=True):
+        """An item's outputs no longer depend (in their last bits) on the batch it travels in
+        (include/ngp.h ``ngp_set_batch_invariant``); applies to jobs staged after the call."""
+        _chk(load().ngp_set_batch_invariant(self._h, 1 if on else 0), "ngp_set_batch_invariant")
 
     def combine_stats(self, reset=False) -> dict:
         out = (C.c_int64 * 4)()

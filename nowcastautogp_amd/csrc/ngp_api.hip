@@ -300,6 +300,7 @@ struct ngp_ctx {
     std::condition_variable comb_arrival;
     bool profiling = false;
     bool toeplitz = true;   // ngp_set_structured_storage
+    bool invariant = false; // ngp_set_batch_invariant (JobGeom::invariant of the jobs staged after)
     ngp_profile prof{};
     size_t mem_cap = 0;  // bytes the factor storage of one job may take
     // caching allocator: repeated jobs of the same shape (the SMC/MCMC loop, the steps of a
@@ -572,6 +573,12 @@ extern "C" ngp_status ngp_set_structured_storage(ngp_ctx *c, int32_t on) {
     c->toeplitz = on != 0;
     return NGP_OK;
 }
+extern "C" ngp_status ngp_set_batch_invariant(ngp_ctx *c, int32_t on) {
+    if (!c) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->invariant = on != 0;
+    return NGP_OK;
+}
 extern "C" ngp_status ngp_profile_enable(ngp_ctx *c, int32_t on) {
     if (!c) return NGP_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -702,7 +709,7 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
     hipStream_t s = ln.main;
     // small chunks of long series: room for the split-k fat steps (chol_col_glds_kernel<.., SPLITK>);
     // the buffer stays with the context
-    if (!half && bc <= AHEAD_EARLY_MAX_ITEMS && !mixed && !g.aux_identity && g.nb0 >= 8 &&
+    if (!half && bc <= AHEAD_EARLY_MAX_ITEMS && !mixed && !g.aux_identity && g.nb0 >= 8 && !g.invariant &&
         ln.ctx->splitk_reserve(bc) == NGP_OK)
         p0.splitk_part = ln.ctx->splitk_part;
     // Small chunks of long series (the 64-particle calls of a fit) are swept as two half-chunks side
@@ -933,6 +940,7 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     if (c->toeplitz && c->spec.precision != NGP_PREC_MIXED) g.toep = toep_stride;
+    g.invariant = c->invariant ? 1 : 0;
     ngp_job *j = new (std::nothrow) ngp_job();
     if (!j) return NGP_ERR_TOO_LARGE;
     j->ctx = c;
@@ -1322,7 +1330,8 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     e.mu = j->mu;
     e.sigma = j->sigma;
     e.work_stride = j->work_stride;
-    if (g.lattice && single_chunk) {   // the tables of the only chunk are still in place
+    // (batch-invariant jobs evaluate the small Schur blocks directly, whatever the number of chunks)
+    if (g.lattice && single_chunk && !g.invariant) {   // the tables of the only chunk are still in place
         e.tab = (const double *)tab;
         e.sig = (const double *)sig;
         e.qpts = j->qpts;
@@ -1865,6 +1874,7 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     j->spec = c->spec;
+    g.invariant = c->invariant ? 1 : 0;
     // (gradient jobs store every tile: their tables are per leaf, and on a regular series the
     // stationary trees — the ones structured storage could serve — are on the Toeplitz path)
     void *q = nullptr;
@@ -1956,7 +1966,7 @@ struct LeafRun {
                // a chunk that is cut finer (split 2 or 4) writes at most 4096 partial rows; a coarse one Bc ntri
                (r = dalloc(&d_part,
                            tp ? 8 * (size_t)Bc * nd * GP
-                              : 8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc),
+                              : 8 * std::max<size_t>((size_t)Bc * ntri * grad_contract_split(ntri, Bc, g.invariant != 0),
                                                      4096) * GP)) ||
                (r = dalloc(&d_items, 4 * (size_t)j->B)));
         return r;
@@ -2032,7 +2042,9 @@ struct LeafRun {
             // (small launches — the 24- or 64-particle calls of a fit on short series — stay ONE launch
             // sized by the largest tree: up to five dependent launches of a few microseconds each cost
             // more there than the occupancy of the smaller instantiations gains)
-            const bool by_size = g.lattice && (tp ? (long)nd * bc > 512 : (long)ntri * bc > 4096);
+            // (batch-invariant jobs: always — an item then runs on the instantiation of ITS tree size,
+            // not on the one the largest tree of its batch picks)
+            const bool by_size = g.lattice && (g.invariant || (tp ? (long)nd * bc > 512 : (long)ntri * bc > 4096));
             int32_t counts[GRAD_BUCKETS] = {};
             if (by_size) {
                 for (int i = 0; i < bc; ++i) ++counts[grad_bucket(j->n_ops[(size_t)(b0 + i)])];
@@ -2142,7 +2154,8 @@ ngp_status grad_pair_run(GradLeaf *a, double *lm_a, double *g_a, int32_t *info_a
     if ((st = ra.layout(take)) || (st = rb.layout(take))) return st;
     // the Toeplitz leaf runs on the value kernels: their split-k fat steps of late columns (small
     // chunks) need the context's buffer, which factor_chunk only reserves for a chunk it owns whole
-    if (b->toep_path && b->g.nb0 >= 8 && b->B <= AHEAD_EARLY_MAX_ITEMS && c->splitk_reserve(b->B) == NGP_OK)
+    if (b->toep_path && b->g.nb0 >= 8 && b->B <= AHEAD_EARLY_MAX_ITEMS && !b->g.invariant &&
+        c->splitk_reserve(b->B) == NGP_OK)
         rb.splitk = c->splitk_part;
     const Lane l0 = lane_of(c);
     const Lane l1{c->lane_main[1], c->lane_side[1], c->lane_fork[1], c->lane_join[1], c};
@@ -2231,10 +2244,11 @@ static ngp_status grad_stage_impl(ngp_ctx *c, int32_t B, const ngp_kernel *kerne
     // blocks, short enough for the weights kernel's LDS image, and a tree without Linear or
     // ChangePoint nodes
     bool regular = false;
-    bool on;
+    bool on, invariant;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         on = c->toeplitz;
+        invariant = c->invariant;
     }
     if (on && n >= 2 * NB && n <= 8192) {
         std::vector<double> real(t, t + n);
@@ -2267,8 +2281,10 @@ static ngp_status grad_stage_impl(ngp_ctx *c, int32_t B, const ngp_kernel *kerne
     // 26.8 -> 25.0 side by side, 256 items 50.2 -> 40.0 and 512 items 98.8 -> 72.0 in turn
     // (scripts/mixed_grad_probe.py).
     constexpr int SPLIT_MIN_ITEMS = 256, PAIR_MIN_ITEMS = 128, PAIR_MIN_N = 1024;
+    // (batch-invariant contexts route by the item alone: a stationary tree on a regular series
+    // always takes the Toeplitz leaf, whatever travels with it)
     if (!j->idx_gen.empty() && !j->idx_toep.empty() && B < SPLIT_MIN_ITEMS) {
-        if (n >= PAIR_MIN_N && B >= PAIR_MIN_ITEMS) {
+        if (invariant || (n >= PAIR_MIN_N && B >= PAIR_MIN_ITEMS)) {
             j->side_by_side = true;
         } else {
             j->idx_toep.clear();

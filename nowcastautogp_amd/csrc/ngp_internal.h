@@ -100,6 +100,10 @@ struct JobGeom {
                        // fill then writes only the diagonal tiles and the aux rows of structured items
                        // (prog_structure) and the column kernels regenerate a tile from 128 numbers in
                        // LDS where they would have read the stored tile (staged fp64 value jobs; else 0)
+    int32_t invariant; // ngp_set_batch_invariant: nothing about an item's arithmetic may depend on
+                       // the size of the batch it travels in (no split-k of small chunks, gradient
+                       // routing and contraction shapes by item / geometry only, the epilogue never
+                       // on the resident tables of a single-chunk job)
     double  h;         // lattice step
     int64_t ld;        // row stride of the factor storage (= n0)
     int64_t item_stride;  // elements per item in the factor storage
@@ -203,7 +207,10 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
                           hipStream_t side = nullptr, hipEvent_t fork = nullptr,
                           hipEvent_t join = nullptr);
 // workgroups per 64x64 tile of the gradient contraction: small launches are cut finer
-inline int grad_contract_split(long ntri, long Bc) {
+// (batch-invariant jobs: by the geometry alone — the split decides how a thread groups its rows,
+// i.e. the order of a partial sum)
+inline int grad_contract_split(long ntri, long Bc, bool invariant = false) {
+    if (invariant) return ntri <= 36 ? 4 : 1;
     return ntri * Bc <= 1024 ? 4 : (ntri * Bc <= 2048 ? 2 : 1);
 }
 void launch_toep_grad(const JobGeom &g, const ChunkPtrs &p, const double *A, double *wbuf,

@@ -2721,7 +2721,7 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
         (void)hipStreamWaitEvent(side, fork, 0);
     }
     if (g.lattice && p.dtab) {
-        const int split = grad_contract_split(ntri, Bc);
+        const int split = grad_contract_split(ntri, Bc, g.invariant != 0);
         nparts = ntri * split;
         // items sorted by tree size (grad_bucket): 1, 2, 4, 8 leaves on the register-accumulator
         // kernel, up to 16 leaves in two passes of it, larger trees on the general kernel

@@ -235,3 +235,42 @@ def test_threaded_per_scenario_loop_is_the_reference_flow(ctx):
     assert a.shape == b.shape == (6, 6 * T) and np.isfinite(b).all()
     assert np.allclose(a, b, rtol=1e-9, atol=1e-9)
     assert st["shared"] > 0 and st["sequences"] < st["requests"]
+
+
+@pytest.mark.parametrize("n,P", [(208, 24), (300, 12), (2048, 64)], ids=["n208x24", "n300x12", "n2048x64"])
+def test_batch_invariant_mode_gives_every_caller_its_own_bits(ctx, n, P):
+    """ngp_set_batch_invariant: an item's logml, gradient and predictive are the same BITS whether
+    its task's call runs alone or shares a launch sequence with seven others (routing between the
+    gradient leaves, split-k, contraction shapes and the epilogue's table use then follow the item
+    and the series alone) — and they still match the oracle."""
+    t, t_new, tasks = _tasks(n, P, seed=100 + n)
+    kas = [KernelArray(p) for p, _ in tasks]
+    ctx.set_batch_invariant(True)
+    try:
+        ctx.set_combining(False)
+        ser_g = [ctx.logml_grad_flat(kas[i], t, tasks[i][1]) for i in range(T)]
+        ser_p = [ctx.predict_batch(tasks[i][0], t, tasks[i][1], t_new) for i in range(T)]
+        ctx.set_combining(True)
+        ctx.combine_stats(reset=True)
+        for _ in range(2):        # the second burst finds company announced by the first
+            com_g, _ = _burst(lambda i: ctx.logml_grad_flat(kas[i], t, tasks[i][1]), [(i,) for i in range(T)])
+            com_p, _ = _burst(lambda i: ctx.predict_batch(tasks[i][0], t, tasks[i][1], t_new),
+                              [(i,) for i in range(T)])
+        st = ctx.combine_stats(reset=True)
+        assert st["shared"] >= T
+        for i in range(T):
+            assert not ser_g[i][2].any() and not com_g[i][2].any()
+            assert np.array_equal(com_g[i][0], ser_g[i][0]), i            # logml
+            assert np.array_equal(com_g[i][1], ser_g[i][1]), i            # gradient
+            for k in range(3):                                            # mean, covariance, logml
+                assert np.array_equal(com_p[i][k], ser_p[i][k]), (i, k)
+        progs, y = tasks[0]
+        off = np.concatenate([[0], np.cumsum(kas[0]._npar + 1)])
+        for b in (0, P - 1):
+            lm_o, g_o, info_o = oracle_np.logml_grad(progs[b], t, y)
+            ev = np.linalg.eigvalsh(oracle_np.cov(progs[b], t, t, add_diag=True))
+            cond = float(ev[-1] / ev[0])
+            check("batch-invariant logml vs oracle", com_g[0][0][b], lm_o, TOL_LOGML, cond)
+            check("batch-invariant gradient vs oracle", com_g[0][1][off[b]:off[b + 1]], g_o, 1e-7, cond)
+    finally:
+        ctx.set_batch_invariant(False)

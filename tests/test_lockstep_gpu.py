@@ -101,6 +101,35 @@ def test_lockstep_equals_the_per_scenario_loop_on_the_hip_engine(eng, mode):
     assert len([c for c in seq if c[0] == "logml_grad"]) == 5 * len(grads)
 
 
+def test_lockstep_is_bit_identical_with_batch_invariant_arithmetic(eng):
+    """The same comparison with ngp_set_batch_invariant on: a P x D lockstep call and D P-item
+    calls give every item the same bits, so the draws are IDENTICAL (the 1e-9 above is what the
+    batch-size-dependent shortcuts cost)."""
+    e = _Counting(eng, shared_k=False)
+    n = 150
+    vals = 100.0 + 0.3 * np.arange(n) + 3.0 * np.sin(np.arange(n) / 7.0) \
+        + np.random.default_rng(5).standard_normal(n)
+    eng.ctx.set_batch_invariant(True)
+    try:
+        base = mc.fitted(e, values=vals, seed=41, n_particles=4, n_mcmc=1, n_hmc=1,
+                         smc_data_proportion=0.5)
+        snap = base.to_dict()
+        scen = nc.create_nowcast_data([[146.0, 147.5], [143.0, 149.0], [148.0, 144.5],
+                                       [145.0, 145.0], [150.0, 141.0]], mc.days(n, n + 2))
+        dates = mc.days(n + 2, n + 8)
+        for mode in (dict(n_hmc=2), dict(n_mcmc=1, n_hmc=1, ess_threshold=1.0)):
+            a = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=e), scen,
+                                          dates, 6, lockstep=True, **mode)
+            b = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=e), scen,
+                                          dates, 6, lockstep=False, **mode)
+            c = nc.forecast_with_nowcasts(nc.GPModel.from_dict(copy.deepcopy(snap), engine=e), scen,
+                                          dates, 6, lockstep=False, threads=4, **mode)
+            assert np.array_equal(a, b), mode
+            assert np.array_equal(b, c), mode
+    finally:
+        eng.ctx.set_batch_invariant(False)
+
+
 def test_lockstep_with_the_resident_factor_weight_update(eng):
     """add_data! of all D clones = ONE query of the base model's resident factor (d appended
     points, no forecast rows)."""
