@@ -1574,27 +1574,35 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const 
     // matter are zero there, so the sum stops at the chunk that holds the last real column
     const int kend = min(g.n0, (g.n_real + LDS_KC - 1) / LDS_KC * LDS_KC);
     const int nchunks = max(kend - kbeg, LDS_KC) / LDS_KC;
+    // Products that are known to be nothing are not issued (the wave still stages its rows and keeps
+    // the barriers; its SIMD's other wave gets the matrix pipe): a wave whose tile lies above the
+    // diagonal of a diagonal block or beyond the last tile, and — W being block upper triangular —
+    // the first 64 columns of the k-range for the waves of row tile I0 + 1, whose rows are the
+    // stored zeros of block (I0 + 1, I0) there.  Adding those zero products changed no bit.
+    const int skip_chunks = __builtin_amdgcn_readfirstlane(!valid ? nchunks : (ltile == 1 ? NB / LDS_KC : 0));
     stage(0, kbeg);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
         if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
         const char *buf = smem + cur * STAGE;
+        if (c >= skip_chunks) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            double a[4];
+            for (int s = 0; s < 4; ++s) {
+                double a[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 2 * BLKB);
+                for (int u = 0; u < 4; ++u)
+                    a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * 2 * BLKB);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                Rot4 br;
-                br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 2 * BLKB);
-                br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 2 * BLKB);
-                br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * 2 * BLKB);
-                br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * 2 * BLKB);
+                for (int it = 0; it < 4; ++it) {
+                    Rot4 br;
+                    br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * 2 * BLKB);
+                    br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * 2 * BLKB);
+                    br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * 2 * BLKB);
+                    br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * 2 * BLKB);
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[jt], br);
+                    for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][it], a[jt], br);
+                }
             }
         }
         __syncthreads();
@@ -2051,7 +2059,12 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
         while (r * (r + 1) / 2 > tile) --r;
         c = tile - r * (r + 1) / 2;
     }
-    const int tx = tid & 63, ty = tid >> 6;
+    // a wave works on ONE row at a time (its 64 lanes are 64 columns): the row index is
+    // wave-uniform, which hipcc cannot see in `tid >> 6` — said explicitly, everything that is a
+    // function of the row alone (t0[row], qpts[row], alpha[row], the ChangePoint sigmoid of the row)
+    // becomes a scalar load instead of a vector load that every lane repeats, and the table lookups
+    // of an element no longer wait behind it (they were two dependent memory round trips per row)
+    const int tx = tid & 63, ty = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = DIAG ? 0 : c * NB + tx;
     const int np = P.n_params;
     const int nops = __builtin_amdgcn_readfirstlane(P.n_ops);
