@@ -422,7 +422,11 @@ typedef struct ngp_profile {
  * Cholesky factor alone — the diagonal sums of K^-1 that the gradient needs follow from its first
  * column (Gohberg-Semencul), n^3/3 flops instead of n^3.  That is other arithmetic, not other
  * storage: logml and gradients agree with the general path to rounding (1e-11 on gradients in the
- * tests), not bit for bit.  Applies to jobs staged after the call.                              */
+ * tests), not bit for bit.  An item qualifies if its tree has no Linear / ChangePoint node and at
+ * most 16 leaves, the series is regular (128 <= n <= 8192) and noise + jitter >= 1e-9 k(0) (the
+ * formula loses about eps cond(K) digits; with the default jitter the guard never binds); which
+ * qualifying items of a MIXED batch actually take it depends on the batch size unless
+ * ngp_set_batch_invariant is on.  Applies to jobs staged after the call. */
 ngp_status ngp_set_structured_storage(ngp_ctx *ctx, int32_t on);
 
 ngp_status ngp_profile_enable(ngp_ctx *ctx, int32_t on);

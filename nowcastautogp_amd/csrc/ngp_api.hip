@@ -2245,10 +2245,12 @@ static ngp_status grad_stage_impl(ngp_ctx *c, int32_t B, const ngp_kernel *kerne
     // ChangePoint nodes
     bool regular = false;
     bool on, invariant;
+    double jitter;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         on = c->toeplitz;
         invariant = c->invariant;
+        jitter = c->spec.jitter;
     }
     if (on && n >= 2 * NB && n <= 8192) {
         std::vector<double> real(t, t + n);
@@ -2267,6 +2269,27 @@ static ngp_status grad_stage_impl(ngp_ctx *c, int32_t B, const ngp_kernel *kerne
         bool stationary = regular && kernels[i].n_ops <= 31;
         for (int k = 0; stationary && k < kernels[i].n_ops; ++k)
             stationary = kernels[i].ops[k] != NGP_OP_LINEAR && kernels[i].ops[k] != NGP_OP_CHANGEPOINT;
+        if (stationary) {
+            // The Gohberg-Semencul sums divide by x_0 = (K^-1)_11 and lose about eps cond(K) of their
+            // digits; cond(K) <= n k(0) / (noise + jitter).  A matrix whose diagonal shift is below
+            // 1e-9 of its diagonal k(0) (reachable only with a jitter far below the default 1e-5: HMC
+            // clamps the noise at 1e-12) is not trusted to that formula and takes the general leaf.
+            double st[NGP_MAX_STACK];
+            int sp_ = 0, pi = 0;
+            for (int k = 0; k < kernels[i].n_ops; ++k) {
+                const int op = kernels[i].ops[k];
+                if (op == NGP_OP_PLUS || op == NGP_OP_TIMES) {
+                    const double b = st[--sp_], a = st[--sp_];
+                    st[sp_++] = op == NGP_OP_PLUS ? a + b : a * b;
+                } else {   // value at distance zero: the constant, or the leaf's amplitude (its last parameter)
+                    const int np = k_nparams[op];
+                    st[sp_++] = std::fabs(kernels[i].params[pi + np - 1]);
+                    pi += np;
+                }
+            }
+            const double k0 = st[0];
+            if (!(kernels[i].noise + jitter >= 1e-9 * k0)) stationary = false;
+        }
         (stationary ? j->idx_toep : j->idx_gen).push_back(i);
     }
     // A batch that is split runs its two leaves one after the other: two chains of dependent launches

@@ -1977,6 +1977,13 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
 // launch sized for the largest tree of the batch would run all of them at its occupancy).
 // f(std::integral_constant<int, I>) for I = FROM, FROM - 1, ..., 0: an unrolled loop by construction
 // (where `#pragma unroll` is a request hipcc may decline, indices here ARE compile-time constants)
+// lane `lane`'s value of v in every lane (two v_readlane_b32; `lane` wave-uniform)
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 template <int FROM, class F>
 __device__ __forceinline__ void static_for_down(F &&f) {
     if constexpr (FROM >= 0) {
@@ -2073,10 +2080,33 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     const double *tab = p.tab + (long)item * g.maxstat * R;
     const double *dt = p.dtab + (long)item * g.maxstat * 3 * R;
     const double *sig = p.sig + (long)item * g.maxcp * npts;
-    // the decoded lists stay in LDS and are read as scalars where they are used (private copies
-    // would sit in scratch wherever hipcc declines to unroll a sweep completely)
-    auto LD = [&](int l) { return (unsigned)__builtin_amdgcn_readfirstlane((int)leaf_dec[l]); };
-    auto BD = [&](int b) { return (unsigned)__builtin_amdgcn_readfirstlane((int)bin_dec[b]); };
+    // The decoded lists.  Trees of one or two leaves (most items of an ensemble) read them ONCE into
+    // scalar registers: every index below is a compile-time constant, so the two arrays are 2 NL - 1
+    // SGPRs, never memory — read from LDS where they are used, every use is an LDS round trip on the
+    // critical path of every row (the compiler barrier at the top of the row loop forbids keeping
+    // them), three to four per node and row.  Larger trees keep the LDS reads: with the words in
+    // registers hipcc hoists everything derived from them as well and spills SGPRs into VGPRs
+    // (<8>: 232 -> 254 VGPRs, one wave per SIMD instead of two).
+    constexpr bool HOIST = NL <= 2;
+    unsigned ldv[HOIST ? NL : 1], bdv[HOIST && NBIN > 0 ? NBIN : 1];
+    if constexpr (HOIST) {
+        static_for_down<NL - 1>([&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            ldv[l] = l < nl ? (unsigned)__builtin_amdgcn_readfirstlane((int)leaf_dec[l]) : 0u;
+        });
+        static_for_down<NBIN - 1>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            bdv[b] = b < nbin ? (unsigned)__builtin_amdgcn_readfirstlane((int)bin_dec[b]) : 0u;
+        });
+    }
+    auto LD = [&](int l) {
+        if constexpr (HOIST) return ldv[l];
+        else return (unsigned)__builtin_amdgcn_readfirstlane((int)leaf_dec[l]);
+    };
+    auto BD = [&](int b) {
+        if constexpr (HOIST) return bdv[b];
+        else return (unsigned)__builtin_amdgcn_readfirstlane((int)bin_dec[b]);
+    };
     auto f_node = [](unsigned d) { return (int)(d & 31u); };
     auto f_op = [](unsigned d) { return (int)((d >> 5) & 15u); };
     auto f_po = [](unsigned d) { return (int)((d >> 9) & 255u); };
@@ -2089,26 +2119,62 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     double gnoise = 0.0;
     const double *Ki = Kinv + (long)item * g.n0 * (DIAG ? 1 : g.n0);
     const double *al = alpha + (long)item * g.n0;
+    // What depends on the row alone — its time, lattice coordinate and alpha — is loaded ONCE per
+    // wave, lane rr holding the values of the wave's row rr, and handed to all lanes by v_readlane
+    // where the row is processed.  Loaded inside the row loop (as until round 4) they were vector
+    // loads that every lane repeats (the compiler barrier below forbids scalar loads: memory may
+    // have changed), and the lattice coordinate stood between the row and its table lookups: two
+    // dependent memory round trips per row where there is now one.
+    const int row0 = DIAG ? 0 : r * NB + ty * 16 + sub * nrows;
+    double t1_l = 0.0, al_l = 0.0;
+    int q1_l = 0;
+    if constexpr (!DIAG) {
+        const int lrow = row0 + (tx < nrows ? tx : 0);      // < n0: inside every array
+        t1_l = p.t0[lrow];
+        q1_l = p.qpts[lrow];
+        al_l = al[lrow];
+    }
+    // ChangePoint sigmoids (trees of up to four leaves): the column's value once per lane, the rows'
+    // values once per wave (lane rr = row rr), instead of two loads per node and row
+    constexpr bool SIGPRE = PREFETCH && NL <= 4 && NBIN > 0 && !DIAG;
+    double sgc[SIGPRE ? NBIN : 1], sgr_l[SIGPRE ? NBIN : 1];
+    if constexpr (SIGPRE) {
+        const int lrow = row0 + (tx < nrows ? tx : 0), lcol = col < g.n0 ? col : 0;
+        static_for_down<NBIN - 1>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            sgc[b] = sgr_l[b] = 0.0;
+            if (b >= nbin) return;
+            const int op = f_op(BD(b));
+            if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
+                sgc[b] = sig[(long)f_slot(BD(b)) * npts + lcol];
+                sgr_l[b] = sig[(long)f_slot(BD(b)) * npts + lrow];
+            }
+        });
+    }
     if (col < g.n_real) {
         const double t2 = p.t0[col], ac = DIAG ? 0.0 : al[col];
         const int q2 = p.qpts[col];
         for (int rr = 0; rr < (DIAG ? 1 : nrows); ++rr) {
-            const int row = DIAG ? (int)blockIdx.x * 256 + tid : r * NB + ty * 16 + sub * nrows + rr;
+            const int row = DIAG ? (int)blockIdx.x * 256 + tid : row0 + rr;
             if (row >= g.n_real || col > row) continue;
             // nothing loop-invariant is to be hoisted out of this loop: with the sweeps unrolled
             // hipcc would keep every node's parameters, constants and table addresses in VGPRs
             // across the rows
             asm volatile("" ::: "memory");
-            double w;
+            double w, t1;
+            int q1;
             if constexpr (DIAG) {
                 w = Ki[row];
+                t1 = p.t0[row];
+                q1 = p.qpts[row];
             } else {
-                w = al[row] * ac - Ki[(long)row * g.n0 + col];
+                t1 = readlane_f64(t1_l, rr);
+                q1 = __builtin_amdgcn_readlane(q1_l, rr);
+                w = readlane_f64(al_l, rr) * ac - Ki[(long)row * g.n0 + col];
                 if (row == col) w *= 0.5;
             }
-            const double t1 = p.t0[row];
             const double d = fabs(t1 - t2);
-            const int dq = abs(p.qpts[row] - q2);
+            const int dq = abs(q1 - q2);
             // ---- every table value of this element requested up front (PREFETCH): read where
             //      the sweeps use them, each leaf's lookups wait out their own round trip — four or
             //      five dependent memory latencies per element, which is what the kernel's time was
@@ -2133,8 +2199,13 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
                     if (b >= nbin) return;
                     const int op = f_op(BD(b));
                     if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
-                        sg[b][0] = sig[(long)f_slot(BD(b)) * npts + row];
-                        sg[b][1] = sig[(long)f_slot(BD(b)) * npts + col];
+                        if constexpr (SIGPRE) {
+                            sg[b][0] = readlane_f64(sgr_l[b], rr);
+                            sg[b][1] = sgc[b];
+                        } else {
+                            sg[b][0] = sig[(long)f_slot(BD(b)) * npts + row];
+                            sg[b][1] = sig[(long)f_slot(BD(b)) * npts + col];
+                        }
                     }
                 });
             }

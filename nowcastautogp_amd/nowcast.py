@@ -14,7 +14,14 @@ and returns every scenario's weight update and predictive mean.  With refinement
 scenario clones advance in LOCKSTEP: every proposal / leapfrog / prediction is one engine call of
 P x D items with per-item y rows — the device sees the reference's whole task fan-out as one batch
 instead of D small ones.  Every clone keeps its own random streams, so the result is that of the
-reference's per-scenario loop (``lockstep=False``) for the same seed.
+reference's per-scenario loop (``lockstep=False``) for the same seed — exactly on an engine whose
+arithmetic does not depend on the batch (the oracle engine of the tests; the HIP engine with
+``ngp_set_batch_invariant``), to rounding otherwise: by default the library picks launch shapes,
+and for gradients the path, by the size of a batch, so an HMC accept decision that sits within
+1e-11 of its threshold can fall the other way (include/ngp.h ``ngp_set_batch_invariant``).
+``lockstep=False, threads=T`` runs the reference's own form — one task per scenario on T threads,
+each making the P-item calls of its clone — and the library combines the concurrent calls
+(include/ngp.h "concurrent callers").
 """
 from __future__ import annotations
 
