@@ -1778,6 +1778,10 @@ struct GradLeaf {
     //   [programs | t | y | lattice indices | info | logdet | gradient | logml]
     unsigned char *io = nullptr;
     size_t o_t = 0, o_y = 0, o_q = 0, o_info = 0, o_logdet = 0, o_grad = 0, o_logml = 0, io_bytes = 0;
+    // lattice jobs: the items by the shape of their reduced program, as in a staged value job
+    // (ascending leaf indices; the fill of the main tiles runs on the value jobs' kernels)
+    std::vector<int32_t> fill_single, fill_chain, fill_other;
+    size_t o_fs = 0, o_fc = 0, o_fo = 0;
     std::vector<unsigned char> h_in, h_out;   // staging copy of a small job's inputs; results
     bool fresh = false;                    // info / logdet still hold the zeros they were staged with
     bool progs_dirty = false;              // set_params since the last upload
@@ -1807,12 +1811,13 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
     j->perm.resize((size_t)B);
     j->n_ops.resize((size_t)B);
     j->n_params.resize((size_t)B);
-    int maxstat = 0, maxcp = 0, maxops = 0;
+    int maxstat = 0, maxcp = 0, maxops = 0, maxtab = 0;
     for (int i = 0; i < B; ++i) {
-        int ns = 0, nc = 0;
-        ngp_status st = compile_program(&kernels[i], &j->hp[(size_t)i], &j->perm[(size_t)i], &ns, &nc);
+        int ns = 0, nc = 0, nt = 0;
+        ngp_status st = compile_program(&kernels[i], &j->hp[(size_t)i], &j->perm[(size_t)i], &ns, &nc, &nt);
         if (st) return st;
         maxstat = std::max(maxstat, ns);
+        maxtab = std::max(maxtab, nt);
         maxcp = std::max(maxcp, nc);
         maxops = std::max(maxops, (int)kernels[i].n_ops);
         j->n_ops[(size_t)i] = kernels[i].n_ops;
@@ -1848,6 +1853,14 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
             g.h = hh;
             g.R = R;
             h_q.resize((size_t)g.n0, 0);
+            // the subtree tables of the reduced programs behind the per-leaf tables (tables_kernel),
+            // and the items sorted by the kernel that fills their main tiles (launch_fill)
+            g.tab_sub = g.maxstat;
+            g.maxstat += maxtab;
+            for (int i = 0; i < B; ++i)
+                (prog_single_table(&j->hp[(size_t)i]) ? j->fill_single
+                                                       : j->hp[(size_t)i].rchain ? j->fill_chain : j->fill_other)
+                    .push_back(i);
         }
     }
     const int ny = g.y_shared ? 1 : B;
@@ -1856,7 +1869,10 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
     j->o_t = al(sizeof(DevProgram) * (size_t)B);
     j->o_y = j->o_t + al(8 * (size_t)g.n0);
     j->o_q = j->o_y + al(8 * (size_t)ny * g.n0);
-    j->o_info = j->o_q + (g.lattice ? al(4 * (size_t)g.n0) : 0);
+    j->o_fs = j->o_q + (g.lattice ? al(4 * (size_t)g.n0) : 0);
+    j->o_fc = j->o_fs + al(4 * j->fill_single.size());
+    j->o_fo = j->o_fc + al(4 * j->fill_chain.size());
+    j->o_info = j->o_fo + al(4 * j->fill_other.size());
     j->o_logdet = j->o_info + al(4 * (size_t)B);
     j->o_grad = j->o_logdet + al(8 * (size_t)B);
     j->o_logml = j->o_grad + al(8 * (size_t)B * GP);
@@ -1870,6 +1886,12 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
         for (int b = 0; b < ny; ++b)
             std::memcpy(hy + (size_t)b * g.n0, yrows ? yrows[b] : y + (int64_t)b * ldy, 8 * (size_t)n);
         if (g.lattice) std::memcpy(j->h_in.data() + j->o_q, h_q.data(), 4 * (size_t)g.n0);
+        if (!j->fill_single.empty())
+            std::memcpy(j->h_in.data() + j->o_fs, j->fill_single.data(), 4 * j->fill_single.size());
+        if (!j->fill_chain.empty())
+            std::memcpy(j->h_in.data() + j->o_fc, j->fill_chain.data(), 4 * j->fill_chain.size());
+        if (!j->fill_other.empty())
+            std::memcpy(j->h_in.data() + j->o_fo, j->fill_other.data(), 4 * j->fill_other.size());
     }
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
@@ -2012,6 +2034,18 @@ struct LeafRun {
             p.qpts = (const int32_t *)d_q;
             p.dtab = (double *)d_dtab;
             p.splitk_part = splitk;
+            if (g.lattice) {   // the chunk's share of the three fill lists
+                auto range = [&](const std::vector<int32_t> &v, size_t off, const int32_t **ptr, int32_t *cnt) {
+                    const auto lo = std::lower_bound(v.begin(), v.end(), b0);
+                    const auto hi = std::lower_bound(v.begin(), v.end(), b0 + bc);
+                    *ptr = (const int32_t *)(io + off) + (lo - v.begin());
+                    *cnt = (int32_t)(hi - lo);
+                };
+                range(j->fill_single, j->o_fs, &p.fill_single, &p.n_fill_single);
+                range(j->fill_chain, j->o_fc, &p.fill_chain, &p.n_fill_chain);
+                range(j->fill_other, j->o_fo, &p.fill_other, &p.n_fill_other);
+                p.fill_base = b0;
+            }
             if (g.lattice) tm.run(4, 0.0, 0.0, [&] { launch_tables(g, p, bc, sp, s); });
             // K's lower blocks, the y' tile row and the zero blocks (a, a-1): the identity block of
             // the aux rows is synthesised by the column kernels, not written

@@ -100,6 +100,8 @@ struct JobGeom {
                        // fill then writes only the diagonal tiles and the aux rows of structured items
                        // (prog_structure) and the column kernels regenerate a tile from 128 numbers in
                        // LDS where they would have read the stored tile (staged fp64 value jobs; else 0)
+    int32_t tab_sub;   // gradient jobs: table slot of the first SUBTREE table (the reduced program's tables
+                       // follow the per-leaf ones, maxstat counts both); value jobs: 0
     int32_t invariant; // ngp_set_batch_invariant: nothing about an item's arithmetic may depend on
                        // the size of the batch it travels in (no split-k of small chunks, gradient
                        // routing and contraction shapes by item / geometry only, the epilogue never

@@ -221,12 +221,14 @@ __global__ __launch_bounds__(256) void tables_kernel(JobGeom g, ChunkPtrs p, Dev
     // gradient jobs: dt = [slot][3][R]: e (the leaf value without its amplitude) and the two
     // factors its lengthscale-type derivatives need, so the O(n^2) contraction is lookups + FMAs
     double *dt = p.dtab ? p.dtab + (long)item * g.maxstat * 3 * g.R : nullptr;
-    if (!dt) {
-        // value job: one table per maximal stationary subtree of the tree (reduced program)
+    if (!dt || g.tab_sub > 0) {
+        // one table per maximal stationary subtree of the tree (reduced program): all a value job
+        // needs; a gradient job keeps them BEHIND its per-leaf tables (slot g.tab_sub on) — its fill
+        // then runs on the reduced-program kernels like a value job's, the contraction on the leaves
         for (int k = 0; k < P.n_tab; ++k) {
             const int first = P.tb_first[k], last = P.tb_last[k];
             for (int idx = threadIdx.x; idx < g.R; idx += 256)
-                tab[(long)k * g.R + idx] = keval_stat(P, sp, first, last, idx * g.h);
+                tab[(long)(g.tab_sub + k) * g.R + idx] = keval_stat(P, sp, first, last, idx * g.h);
         }
     }
     int pi = 0;
@@ -2650,9 +2652,38 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
     if (g.lattice) {
         const long nwg = (long)(ntiles - off) * Bc;
         const int split = nwg <= 1024 ? 4 : (nwg <= 2048 ? 2 : 1);
-        if (p.dtab) {
+        if (p.dtab && p.fill_other && !aux_only) {
+            // Gradient jobs: the main tiles through the kernels of the value jobs — one lookup for a
+            // stationary tree, chain programs decoded once per thread for sixteen elements, the
+            // rest on the reduced program — reading the subtree tables behind the per-leaf ones;
+            // the values are those of the full program, operation for operation (keval_stat).  The
+            // full-program interpreter decodes every node for every element from LDS: 8 us per item
+            // at n = 2049 against 4.  The aux tiles (y', the zero blocks, e_1') hold no covariance.
+            ChunkPtrs q = p;
+            q.tab = p.tab + (size_t)g.tab_sub * g.R;
+            q.dtab = nullptr;
+            const long nwg_o = (long)ntri * p.n_fill_other;
+            const int split_o = nwg_o <= 1024 ? 4 : (nwg_o <= 2048 ? 2 : 1);
+            if (p.n_fill_other > 0)
+                hipLaunchKernelGGL(fill_lattice_kernel<false>, dim3(ntri * split_o, p.n_fill_other),
+                                   dim3(256), 0, s, g, q, ntri, 0, split_o, sp);
+            if (p.n_fill_chain > 0)
+                hipLaunchKernelGGL(fill_chain_kernel, dim3(ntri, p.n_fill_chain), dim3(256), 0, s, g, q,
+                                   ntri, sp);
+            if (p.n_fill_single > 0)
+                hipLaunchKernelGGL(fill_single_kernel, dim3(ntri, p.n_fill_single), dim3(256), 0, s, g,
+                                   q, ntri, sp);
+            ChunkPtrs a = p;
+            a.fill_other = nullptr;
+            const long nwg_a = (long)(ntiles - ntri) * Bc;
+            const int split_a = nwg_a <= 1024 ? 4 : (nwg_a <= 2048 ? 2 : 1);
+            hipLaunchKernelGGL(fill_lattice_kernel<true>, dim3((ntiles - ntri) * split_a, Bc), dim3(256),
+                               0, s, g, a, ntri, ntri, split_a, sp);
+        } else if (p.dtab) {
+            ChunkPtrs q = p;
+            q.fill_other = nullptr;
             hipLaunchKernelGGL(fill_lattice_kernel<true>, dim3((ntiles - off) * split, Bc), dim3(256),
-                               0, s, g, p, ntri, off, split, sp);
+                               0, s, g, q, ntri, off, split, sp);
         } else if (p.fill_other && !aux_only) {
             // staged value jobs: chain programs on their own kernel, the rest element by element
             if (p.n_fill_other > 0)
