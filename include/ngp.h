@@ -147,7 +147,11 @@ ngp_status  ngp_kernel_check(const ngp_kernel *k);
  * reach batches of P x (concurrent tasks) items.  A result is the one a single call over the combined
  * items would give: equal to the caller's own call up to the last bits (batch size decides
  * launch shapes and therefore summation order, as it always did — see DESIGN.md section 4.14).
- * ngp_set_combining(ctx, 0) switches it off (every call then waits for ctx's lock and runs alone).
+ * ngp_set_combining(ctx, 0) switches it off (every call then waits for ctx's lock and runs alone);
+ * 1 (default) is as described; 2 combines what is pending but never waits for company (without the
+ * wait a convoy of T tasks alternates between groups of 1 and T - 1: measured 1.45 x slower at
+ * 8 x 24 items, n = 208 (380 launch sequences instead of 200), 1.08 x at 16 x 64 items, n = 2048 —
+ * profiles/r04/combine_linger_ab.txt).
  * ngp_combine_stats: out4 = { requests seen, launch sequences run for them, largest group,
  * requests that shared a sequence with at least one other }; reset != 0 clears the counters.  */
 ngp_status ngp_set_combining(ngp_ctx *ctx, int32_t on);

@@ -583,8 +583,8 @@ class Context:
     # ---- measurement ----------------------------------------------------------------------
     def set_combining(self, on=True):
         """Combining of concurrent one-shot callers (include/ngp.h "concurrent callers"); on by
-        default."""
-        _chk(load().ngp_set_combining(self._h, 1 if on else 0), "ngp_set_combining")
+        default.  ``on``: False / 0 off, True / 1 on, 2 on without the bounded wait for company."""
+        _chk(load().ngp_set_combining(self._h, int(on)), "ngp_set_combining")
 
     def set_batch_invariant(self, on=True):
         """An item's outputs no longer depend (in their last bits) on the batch it travels in

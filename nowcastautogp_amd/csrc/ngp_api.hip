@@ -292,7 +292,7 @@ struct ngp_ctx {
     // fields only and is never held across a device call; mu stays the execution lock.
     std::mutex qmu;
     std::vector<ngp_comb_req *> pending;
-    bool combining = false, combine_on = true;
+    bool combining = false, combine_on = true, combine_linger = true;
     int64_t comb_stats[4] = {};   // requests | launch sequences | largest group | requests that shared one
     // company seen lately: the number of requests the last server took (decays when a wait for
     // it was in vain) and the condition a would-be server waits on for at most COMB_LINGER_US
@@ -2859,7 +2859,7 @@ ngp_status combine_submit(ngp_ctx *c, ngp_comb_req &r) {
             continue;
         }
         c->combining = true;
-        if (c->pending.size() < c->comb_expect) {
+        if (c->combine_linger && c->pending.size() < c->comb_expect) {
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(COMB_LINGER_US);
             (void)c->comb_arrival.wait_until(q, deadline, [&] { return c->pending.size() >= c->comb_expect; });
         }
@@ -2893,6 +2893,7 @@ extern "C" ngp_status ngp_set_combining(ngp_ctx *c, int32_t on) {
     if (!c) return NGP_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->qmu);
     c->combine_on = on != 0;
+    c->combine_linger = on != 2;   // 2: combine what is pending, never wait for company
     return NGP_OK;
 }
 

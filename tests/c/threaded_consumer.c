@@ -6,7 +6,7 @@
  * "concurrent callers"), checks that every thread gets — to rounding: batch size decides launch
  * shapes — what it gets alone, and checks thread 0's first item against the C oracle.
  * Built and run by tests/test_combine_gpu.py::test_threaded_c_host; prints one line per size that
- * the test parses.  usage: threaded_consumer T K n P */
+ * the test parses.  usage: threaded_consumer T K n P [combining mode: 1 (default) | 2 = never wait for company] */
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -60,7 +60,8 @@ static double run_all(task_t *tk, int T) {
 
 int main(int argc, char **argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 8, K = argc > 2 ? atoi(argv[2]) : 20,
-              n = argc > 3 ? atoi(argv[3]) : 208, P = argc > 4 ? atoi(argv[4]) : 24;
+              n = argc > 3 ? atoi(argv[3]) : 208, P = argc > 4 ? atoi(argv[4]) : 24,
+              mode = argc > 5 ? atoi(argv[5]) : 1;   /* ngp_set_combining mode of the "together" run */
     if (T < 1 || T > 64 || K < 1 || n < 2 || P < 1) return 2;
     ngp_ctx *ctx = NULL;
     if (ngp_ctx_create(0, &ctx) != NGP_OK) { printf("no device\n"); return 2; }
@@ -108,7 +109,7 @@ int main(int argc, char **argv) {
         for (int p = 0; p < P; ++p) if (tk[i].info[p] != 0) ++fails;
     }
     /* together */
-    ngp_set_combining(ctx, 1);
+    ngp_set_combining(ctx, mode);
     (void)run_all(tk, T);
     int64_t st4[4];
     ngp_combine_stats(ctx, st4, 1);
