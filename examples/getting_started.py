@@ -57,6 +57,18 @@ def main():
     lo, med, hi = np.quantile(fcn, [0.05, 0.5, 0.95], axis=1)
     for k in range(horizon):
         print(f"  {dates[n + k]}  median {med[k]:8.1f}  90% [{lo[k]:8.1f}, {hi[k]:8.1f}]  truth {counts[n + k]:8.1f}")
+    # "Approach 5" of the reference's vignette (docs/vignettes/getting-started.jl:631-634): HMC
+    # refinement of every scenario's particles after its nowcast.  Three ways to run the same thing:
+    # the lockstep ensemble (one call of P x D items per leapfrog), the reference's own form — one
+    # task per scenario, here on 8 threads, whose concurrent P-item calls the library combines — and
+    # the same tasks one after another.
+    for label, kw in (("lockstep ensemble", dict()), ("one task per scenario, 8 threads", dict(lockstep=False, threads=8)),
+                      ("one scenario after another", dict(lockstep=False))):
+        t0 = time.perf_counter()
+        fr = nc.forecast_with_nowcasts(model, nowcasts, dates[n:n + horizon], 20,
+                                       inv_transformation=inv_transformation, n_hmc=1, **kw)
+        print(f"forecast_with_nowcasts(n_hmc=1), {label}: {time.perf_counter() - t0:.2f} s, "
+              f"median of week 1 {np.median(fr[0]):.1f}")
 
 
 if __name__ == "__main__":
