@@ -5,7 +5,10 @@ PARITY UNPINNED: AutoGP.jl (reference Project.toml:7,15), which holds this arith
 available here and the reference's tests pin no numeric GP output; this module restates the
 textbook identities and the recalled kernel grammar a second time,
 sharing no code with ``ngp_oracle.c``, so that the two agreeing (<= 1e-12 rel on the committed
-fixtures, tests/test_oracle.py) is the parity anchor available.
+fixtures, tests/test_oracle.py) is the parity anchor available.  What the grammar shares with
+textbook GP regression — the identities and five of the eight closed forms — is additionally
+checked against scikit-learn's GaussianProcessRegressor (tests/test_oracle_sklearn.py): an outside
+implementation, not the reference.
 
 It is also the CPU baseline of ``bench.py``: the same LAPACK family Julia's LinearAlgebra uses
 (OpenBLAS ``dpotrf``/``dpotrs``), run the way the reference runs it — BLAS threads = 1
