@@ -241,7 +241,7 @@ def _is_stationary(prog):
     return len(prog[0]) <= 31 and not any(int(o) in (2, 8) for o in prog[0])
 
 
-def _check_gradient_batch(eng, progs, tt, Y, tag, expect_pair=False):
+def _check_gradient_batch(eng, progs, tt, Y, tag, expect_pair=False, spread=12):
     """stage -> run once -> oracle parity on the first and last item of every memory-driven chunk
     of every leaf + 12 spread items; finite and status 0 on ALL items"""
     from nowcastautogp_amd._abi import KernelArray
@@ -262,7 +262,7 @@ def _check_gradient_batch(eng, progs, tt, Y, tag, expect_pair=False):
     assert lay["general_items"] == gen_idx.size
     if gen_idx.size:
         leaves.append((gen_idx, lay["general_chunk"]))
-    picks = {int(v) for v in np.linspace(0, B - 1, 12)}
+    picks = {int(v) for v in np.linspace(0, B - 1, spread)}
     nchunks = []
     for idx, chunk in leaves:
         assert chunk > 0
@@ -289,13 +289,14 @@ def _check_gradient_batch(eng, progs, tt, Y, tag, expect_pair=False):
 def test_headline_c3_gradient_batch_against_the_oracle(eng, ensemble):
     """BASELINE.json configs[2] as ``bench.py --mode grad`` runs it: the 12,800 (particle, scenario)
     items as ONE resident gradient job — both leaves on the prior ensemble (stationary trees on the
-    Toeplitz path, the others general), every memory-driven chunk — run once; and the same on the
+    Toeplitz path, the others general), every memory-driven chunk, 12 spread items — run once; and the same (6 spread items) on the
     'fitted' ensemble (no stationary tree: what ``mcmc_parameters!`` on a fitted model evaluates,
     reference src/forecasting.jl:145-148).  Stated tolerances: logml 1e-10, gradient 1e-7 normwise
     per item, both condition-aware and recorded (tests/util.check)."""
     w, progs, Y, tt = bench_items("C3", 0, ensemble=ensemble)
     assert len(progs) == 12800 and tt.size == 2049
-    lay, nchunks = _check_gradient_batch(eng, progs, tt, Y, f"test_headline_c3_gradient_batch[{ensemble}]")
+    lay, nchunks = _check_gradient_batch(eng, progs, tt, Y, f"test_headline_c3_gradient_batch[{ensemble}]",
+                                         spread=12 if ensemble == "prior" else 6)
     if ensemble == "prior":
         assert lay["toeplitz_items"] > 0 and lay["general_items"] > 0
     else:
@@ -308,4 +309,4 @@ def test_mixed_batch_of_160_items_runs_its_leaves_side_by_side_against_the_oracl
     (grad_pair_run) — checked against the oracle itself, not only against the general path."""
     w, progs, Y, tt = bench_items("C3", 0, P=32, D=5)
     assert len(progs) == 160
-    _check_gradient_batch(eng, progs, tt, Y, "test_mixed_batch_160_side_by_side", expect_pair=True)
+    _check_gradient_batch(eng, progs, tt, Y, "test_mixed_batch_160_side_by_side", expect_pair=True, spread=5)
