@@ -318,6 +318,23 @@ def fit_forecast_wallclock(w, device, rank, args):
         lt["combining"] = eng.ctx.combine_stats(reset=True)
         lt["finite_and_shaped"] = bool(np.isfinite(ft).all()) and ft.shape == (m, D * 20)
         lt["over_lockstep"] = lt["gpu_s"] / legs["forecast_with_nowcasts_hmc"]["gpu_s"]
+        # ... and the DEFAULT mode (n_mcmc = n_hmc = 0, src/forecasting.jl:120) the same way: every
+        # task's add_data! and predict_mvn reach the library with the particles of the same model
+        # and its own nowcast values — recognised and served from one factorisation per particle
+        eng.ctx.combine_stats(reset=True)
+        fd = timed("forecast_with_nowcasts_default_threads",
+                   lambda: nc.forecast_with_nowcasts(model, scen, fdates, 20, lockstep=False, threads=thr),
+                   settings={"scenarios": D, "particles": P, "draws_per_scenario": 20, "lockstep": False,
+                             "threads": thr})
+        ld_ = legs["forecast_with_nowcasts_default_threads"]
+        ld_["combining"] = eng.ctx.combine_stats(reset=True)
+        ld_["finite_and_shaped"] = bool(np.isfinite(fd).all()) and fd.shape == (m, D * 20)
+        ld_["one_call_form_s"] = legs["forecast_with_nowcasts_first"]["gpu_s"]
+        eng.ctx.set_combining(False)
+        timed("forecast_with_nowcasts_default_threads_not_combined",
+              lambda: nc.forecast_with_nowcasts(model, scen, fdates, 20, lockstep=False, threads=thr),
+              settings={"scenarios": D, "particles": P, "lockstep": False, "threads": thr, "combining": False})
+        eng.ctx.set_combining(True)
         # the everyday size (docs/vignettes/getting-started.jl:266-268, 543): a few hundred points,
         # 24 particles, 100 scenarios — lockstep against the unchanged per-scenario tasks
         nv = 208

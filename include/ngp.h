@@ -152,8 +152,16 @@ ngp_status  ngp_kernel_check(const ngp_kernel *k);
  * wait a convoy of T tasks alternates between groups of 1 and T - 1: measured 1.45 x slower at
  * 8 x 24 items, n = 208 (380 launch sequences instead of 200), 1.08 x at 16 x 64 items, n = 2048 —
  * profiles/r04/combine_linger_ab.txt).
- * ngp_combine_stats: out4 = { requests seen, launch sequences run for them, largest group,
- * requests that shared a sequence with at least one other }; reset != 0 clears the counters.  */
+ * A group of logml or predictive requests that carry THE SAME kernels (byte for byte) and whose
+ * observations differ only in their last few points — the scenario tasks of the reference's default
+ * mode, n_mcmc = n_hmc = 0 (src/forecasting.jl:120, 133-155): clones of one model, each with its own
+ * nowcast values on shared dates (src/create_nowcast_data.jl:36-37) — is served by ONE factorisation
+ * per particle with the tasks' last points as scenarios (the arithmetic of ngp_nowcast_batch), not by
+ * one factorisation per (particle, task): K does not depend on y.  Results equal the caller's own
+ * call to rounding (1e-8 on predictive moments in the tests, condition-aware).
+ * ngp_combine_stats: out6 = { requests seen, launch sequences run for them, largest group,
+ * requests that shared a sequence with at least one other, requests served from one shared
+ * factorisation per particle, reserved }; reset != 0 clears the counters.                      */
 ngp_status ngp_set_combining(ngp_ctx *ctx, int32_t on);
 /* Batch-invariant arithmetic (off by default; applies to jobs staged after the call).  By default
  * a few decisions follow the size of the batch an item travels in, for speed: late block columns of
@@ -168,7 +176,7 @@ ngp_status ngp_set_combining(ngp_ctx *ctx, int32_t on);
  * combined group (tests/test_combine_gpu.py, tests/test_lockstep_gpu.py), at the price of the
  * small-batch shortcuts (64 items at n = 2048: see DESIGN.md section 4.14).                    */
 ngp_status ngp_set_batch_invariant(ngp_ctx *ctx, int32_t on);
-ngp_status ngp_combine_stats(ngp_ctx *ctx, int64_t *out4, int32_t reset);
+ngp_status ngp_combine_stats(ngp_ctx *ctx, int64_t *out6, int32_t reset);
 
 /* ---- covariance assembly (diagnostic / small blocks) ---------------------
  * out[b] (n1 x n2, row-major) = k_b(t1_i, t2_j) (+ (noise_b + jitter) on the

@@ -110,7 +110,8 @@ Concurrent callers (include/ngp.h): one-shot calls entered from several tasks at
 `Threads.@spawn` per scenario of the reference's `forecast_with_nowcasts`, src/forecasting.jl:131-159
 — are combined inside libngp into one launch sequence per group of compatible requests.  On by
 default; `set_combining(ctx, false)` makes every call wait for the context and run alone.
-`combine_stats(ctx)` = (requests, launch sequences, largest group, requests that shared one).
+`combine_stats(ctx)` = (requests, launch sequences, largest group, requests that shared one, requests
+served from one shared factorisation per particle).
 """
 set_combining(c::Context, on::Bool) =
     check(ccall((:ngp_set_combining, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on), "ngp_set_combining")
@@ -119,10 +120,11 @@ set_batch_invariant(c::Context, on::Bool) =
     check(ccall((:ngp_set_batch_invariant, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on),
           "ngp_set_batch_invariant")
 function combine_stats(c::Context; reset::Bool = false)
-    out = zeros(Int64, 4)
+    out = zeros(Int64, 6)
     check(ccall((:ngp_combine_stats, LIBNGP), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int32), c.h, out, reset),
           "ngp_combine_stats")
-    return (requests = out[1], sequences = out[2], largest_group = out[3], shared = out[4])
+    return (requests = out[1], sequences = out[2], largest_group = out[3], shared = out[4],
+            shared_k = out[5])
 end
 
 "storage option of staged value jobs (include/ngp.h): results are bit-identical either way"

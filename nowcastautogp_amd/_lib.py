@@ -592,10 +592,10 @@ class Context:
         _chk(load().ngp_set_batch_invariant(self._h, 1 if on else 0), "ngp_set_batch_invariant")
 
     def combine_stats(self, reset=False) -> dict:
-        out = (C.c_int64 * 4)()
+        out = (C.c_int64 * 6)()
         _chk(load().ngp_combine_stats(self._h, out, 1 if reset else 0), "ngp_combine_stats")
         return dict(requests=int(out[0]), sequences=int(out[1]), largest_group=int(out[2]),
-                    shared=int(out[3]))
+                    shared=int(out[3]), shared_k=int(out[4]))
 
     def set_structured_storage(self, on=True):
         """Storage option of staged value jobs (include/ngp.h): results are bit-identical either way."""

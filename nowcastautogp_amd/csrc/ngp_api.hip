@@ -293,7 +293,8 @@ struct ngp_ctx {
     std::mutex qmu;
     std::vector<ngp_comb_req *> pending;
     bool combining = false, combine_on = true, combine_linger = true;
-    int64_t comb_stats[4] = {};   // requests | launch sequences | largest group | requests that shared one
+    int64_t comb_stats[6] = {};   // requests | launch sequences | largest group | requests that shared one |
+                                  // requests served from ONE factorisation per particle | (reserved)
     // company seen lately: the number of requests the last server took (decays when a wait for
     // it was in vain) and the condition a would-be server waits on for at most COMB_LINGER_US
     size_t comb_expect = 1;
@@ -2720,8 +2721,9 @@ ngp_status comb_run_one(ngp_ctx *c, ngp_comb_req &r) {
 }
 
 // a group of compatible requests as ONE call; the results go back to every request's own arrays
-ngp_status comb_run_group(ngp_ctx *c, const std::vector<ngp_comb_req *> &grp) {
+ngp_status comb_run_group(ngp_ctx *c, const std::vector<ngp_comb_req *> &grp, bool *shared_k) {
     const ngp_comb_req &r0 = *grp[0];
+    *shared_k = false;
     if (r0.kind == CK_MIXTURE) {
         // K mixtures of P components each = ngp_mixture_sample_indep with one seed per request
         const size_t K = grp.size(), P = (size_t)r0.P, m = (size_t)r0.m, dr = (size_t)r0.draws;
@@ -2744,6 +2746,70 @@ ngp_status comb_run_group(ngp_ctx *c, const std::vector<ngp_comb_req *> &grp) {
             if (grp[a]->info) std::memcpy(grp[a]->info, info.data() + a * P, 4 * P);
         }
         return NGP_OK;
+    }
+    // ---- the scenario tasks of the reference's DEFAULT mode (n_mcmc = n_hmc = 0, src/forecasting.jl:120):
+    // every task holds a clone of the same model — the same trees and parameters — on the same
+    // dates, and its observations differ from the others' only in the appended nowcast points
+    // (src/create_nowcast_data.jl:36-37).  K does not depend on y: such a group is ONE factorisation
+    // per particle with the tasks' appended observations as scenarios — the shared-K form of
+    // ngp_nowcast_batch (SURVEY.md section 8d "dedupe rule") — instead of one per (particle, task).
+    // Recognised, not assumed: same kernels byte for byte, one y per request, a common prefix of the
+    // observations up to a few last points.  Not under ngp_set_batch_invariant (another route to the
+    // same numbers: equal to rounding, not bit for bit).
+    bool invariant;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        invariant = c->invariant;
+    }
+    if ((r0.kind == CK_LOGML || r0.kind == CK_PREDICT) && !invariant) {
+        constexpr int SHARED_K_MAX_TAIL = 16;
+        bool same = true;
+        for (size_t a = 1; a < grp.size() && same; ++a) {
+            const ngp_comb_req &r = *grp[a];
+            same = r.B == r0.B && r.ldy == 0 && r0.ldy == 0;
+            for (int b = 0; same && b < r.B; ++b) {
+                const ngp_kernel &ka = r0.k[b], &kb = r.k[b];
+                same = ka.n_ops == kb.n_ops && ka.n_params == kb.n_params && ka.noise == kb.noise &&
+                       std::memcmp(ka.ops, kb.ops, 4 * (size_t)ka.n_ops) == 0 &&
+                       (ka.n_params == 0 || std::memcmp(ka.params, kb.params, 8 * (size_t)ka.n_params) == 0);
+            }
+        }
+        int npre = r0.n;   // observations every request shares
+        for (size_t a = 1; a < grp.size() && same; ++a) {
+            int i = 0;
+            while (i < npre && grp[a]->y[i] == r0.y[i]) ++i;
+            npre = i;
+        }
+        int dt = std::max(r0.n - npre, 1);
+        npre = r0.n - dt;
+        if (same && grp[0]->ldy == 0 && dt <= SHARED_K_MAX_TAIL && npre >= 1 &&
+            (npre % NB) + dt + r0.m + 1 <= NGP_MAX_AUX) {
+            const size_t P = (size_t)r0.B, D = grp.size(), m = (size_t)r0.m;
+            std::vector<double> yadd(D * (size_t)dt), lf(P * D), mu(P * D * m), sg(P * m * m);
+            std::vector<int32_t> info(P);
+            for (size_t a = 0; a < D; ++a) std::memcpy(yadd.data() + a * dt, grp[a]->y + npre, 8 * (size_t)dt);
+            ngp_job *job = nullptr;
+            ngp_status st = stage_general(c, (int)P, r0.k, npre, r0.t, r0.y, 0, dt, r0.t + npre, (int)D,
+                                          yadd.data(), 0, r0.m, r0.t_new, r0.noise_on_new, &job);
+            if (!st) {
+                st = ngp_job_run(job);
+                if (!st) st = ngp_job_fetch(job, nullptr, lf.data(), m ? mu.data() : nullptr,
+                                            m ? sg.data() : nullptr, info.data());
+                ngp_job_destroy(job);
+            }
+            if (st) return st;
+            for (size_t a = 0; a < D; ++a) {
+                ngp_comb_req *r = grp[a];
+                for (size_t b = 0; b < P; ++b) {
+                    if (r->logml) r->logml[b] = lf[b * D + a];
+                    if (m && r->mu) std::memcpy(r->mu + b * m, mu.data() + (b * D + a) * m, 8 * m);
+                }
+                if (m && r->sigma) std::memcpy(r->sigma, sg.data(), 8 * P * m * m);
+                if (r->info) std::memcpy(r->info, info.data(), 4 * P);
+            }
+            *shared_k = true;
+            return NGP_OK;
+        }
     }
     size_t Bt = 0;
     for (const ngp_comb_req *r : grp) Bt += (size_t)r->B;
@@ -2803,7 +2869,7 @@ ngp_status comb_run_group(ngp_ctx *c, const std::vector<ngp_comb_req *> &grp) {
 }
 
 // everything one server took from `pending`: groups in order of their first member's arrival
-void comb_execute(ngp_ctx *c, const std::vector<ngp_comb_req *> &batch, int64_t stats[4]) {
+void comb_execute(ngp_ctx *c, const std::vector<ngp_comb_req *> &batch, int64_t stats[6]) {
     std::vector<char> taken(batch.size(), 0);
     for (size_t i = 0; i < batch.size(); ++i) {
         if (taken[i]) continue;
@@ -2816,9 +2882,11 @@ void comb_execute(ngp_ctx *c, const std::vector<ngp_comb_req *> &batch, int64_t 
             }
         stats[0] += (int64_t)grp.size();
         if (grp.size() > 1) {
-            const ngp_status st = comb_run_group(c, grp);
+            bool shared_k = false;
+            const ngp_status st = comb_run_group(c, grp, &shared_k);
             if (st == NGP_OK) {
                 for (ngp_comb_req *r : grp) r->st = NGP_OK;
+                if (shared_k) stats[4] += (int64_t)grp.size();
                 stats[1] += 1;
                 stats[2] = std::max<int64_t>(stats[2], (int64_t)grp.size());
                 stats[3] += (int64_t)grp.size();
@@ -2867,13 +2935,14 @@ ngp_status combine_submit(ngp_ctx *c, ngp_comb_req &r) {
         batch.swap(c->pending);
         c->comb_expect = std::max<size_t>(batch.size(), 1);
         q.unlock();
-        int64_t stats[4] = {0, 0, 0, 0};
+        int64_t stats[6] = {0, 0, 0, 0, 0, 0};
         comb_execute(c, batch, stats);
         q.lock();
         c->comb_stats[0] += stats[0];
         c->comb_stats[1] += stats[1];
         c->comb_stats[2] = std::max(c->comb_stats[2], stats[2]);
         c->comb_stats[3] += stats[3];
+        c->comb_stats[4] += stats[4];
         // (qmu is held from `done = true` to the notify: a woken caller cannot leave — and take its
         // request off its stack — before this loop is through with it)
         for (ngp_comb_req *x : batch) {
@@ -2897,11 +2966,11 @@ extern "C" ngp_status ngp_set_combining(ngp_ctx *c, int32_t on) {
     return NGP_OK;
 }
 
-extern "C" ngp_status ngp_combine_stats(ngp_ctx *c, int64_t *out4, int32_t reset) {
-    if (!c || !out4) return NGP_ERR_ARG;
+extern "C" ngp_status ngp_combine_stats(ngp_ctx *c, int64_t *out6, int32_t reset) {
+    if (!c || !out6) return NGP_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->qmu);
-    for (int i = 0; i < 4; ++i) out4[i] = c->comb_stats[i];
-    if (reset) for (int i = 0; i < 4; ++i) c->comb_stats[i] = 0;
+    for (int i = 0; i < 6; ++i) out6[i] = c->comb_stats[i];
+    if (reset) for (int i = 0; i < 6; ++i) c->comb_stats[i] = 0;
     return NGP_OK;
 }
 

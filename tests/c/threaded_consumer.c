@@ -111,7 +111,7 @@ int main(int argc, char **argv) {
     /* together */
     ngp_set_combining(ctx, mode);
     (void)run_all(tk, T);
-    int64_t st4[4];
+    int64_t st4[6];
     ngp_combine_stats(ctx, st4, 1);
     const double on_s = run_all(tk, T);
     ngp_combine_stats(ctx, st4, 1);

@@ -56,12 +56,20 @@ constexpr double POISON = -777.25;
 constexpr int P = 3, NG = 6 + 7 + 8 + 3;   // gradient entries of the ensemble
 
 // kind: 0 logml, 1 logml + gradient, 2 predict, 3 mixture sample, 4 a resident gradient job run
-// three times (the leapfrog steps of one HMC move); `n` picks the dates
-static void one_call(ngp_ctx *ctx, int kind, int n, int id) {
+// three times (the leapfrog steps of one HMC move), 5 / 6 logml / predict of scenario clones (same
+// trees, observations that differ in their last two points only: served from one shared
+// factorisation per particle); `n` picks the dates
+static void one_call(ngp_ctx *ctx, int kind_in, int n, int id) {
+    int kind = kind_in;
     Ensemble e;
     const int m = 4, draws = 5;
     std::vector<double> t(n), y(n), t_new(m);
-    for (int i = 0; i < n; ++i) { t[i] = (double)i / (n - 1); y[i] = std::sin(9.0 * t[i] + id); }
+    const bool clones = kind >= 5;
+    for (int i = 0; i < n; ++i) {
+        t[i] = (double)i / (n - 1);
+        y[i] = std::sin(9.0 * t[i] + (clones && i < n - 2 ? 0 : id));
+    }
+    if (clones) kind = kind == 5 ? 0 : 2;
     for (int i = 0; i < m; ++i) t_new[i] = 1.0 + (double)(i + 1) / (n - 1);
     // every output array carries one guard element behind its end
     std::vector<double> lm(P + 1, POISON), grad(NG + 1, POISON), mu(P * m + 1, POISON),
@@ -127,7 +135,7 @@ static void burst(ngp_ctx *ctx, int T, const std::vector<int> &kinds, const std:
 int main() {
     ngp_ctx *ctx = nullptr;
     if (ngp_ctx_create(0, &ctx) != NGP_OK) return 2;
-    int64_t st4[4];
+    int64_t st4[6];
     const int T = 8;
 
     // reference: launches of ONE gradient call alone
@@ -160,6 +168,15 @@ int main() {
     std::printf("resident jobs: %lld runs in %lld launch sequences, largest group %lld\n", (long long)st4[0],
                 (long long)st4[1], (long long)st4[2]);
     CHECK(st4[2] >= T / 2 && st4[1] < st4[0], "concurrent runs of resident jobs were not combined");
+
+    // (1c) scenario clones: same trees, observations equal up to the last two points
+    mock_hip_set_sync_delay_us(5000);
+    l0 = mock_hip_launches();
+    burst(ctx, T, {5, 6}, {200}, 3);
+    CHECK(ngp_combine_stats(ctx, st4, 1) == NGP_OK && st4[0] == T * 3, "requests of the clone rounds");
+    std::printf("scenario clones: %lld requests, %lld sequences, %lld served from a shared factorisation\n",
+                (long long)st4[0], (long long)st4[1], (long long)st4[4]);
+    CHECK(st4[4] >= T, "clones of one model were not served from one factorisation per particle");
 
     // (2) many rounds, every combinable entry point, two different series at once: nobody is lost
     mock_hip_set_sync_delay_us(300);

@@ -274,3 +274,78 @@ def test_batch_invariant_mode_gives_every_caller_its_own_bits(ctx, n, P):
             check("batch-invariant gradient vs oracle", com_g[0][1][off[b]:off[b + 1]], g_o, 1e-7, cond)
     finally:
         ctx.set_batch_invariant(False)
+
+
+def test_scenario_clones_are_served_from_one_factorisation_per_particle(ctx):
+    """The reference's DEFAULT mode (n_mcmc = n_hmc = 0, reference src/forecasting.jl:120, 133-155): every
+    scenario task holds a clone of the same model and its own nowcast values on shared dates
+    (reference src/create_nowcast_data.jl:36-37).  Concurrent logml / predictive calls with the SAME kernels
+    and observations that differ in the last points only are recognised and served from ONE
+    factorisation per particle (K does not depend on y) — the arithmetic of ngp_nowcast_batch; every
+    task still gets what its own call returns, to the stated tolerances."""
+    n, P, d = 700, 16, 2
+    w = make_workload("C3", n=n, P=P, D=T, d=d, m=5, seed_offset=9)
+    t = np.concatenate([w.t, w.t_add])
+    ys = [np.concatenate([w.y, w.y_add[s]]) for s in range(T)]
+    progs = w.programs
+    ctx.set_combining(False)
+    t0 = time.perf_counter()
+    ser_l = [ctx.logml_batch(progs, t, ys[s]) for s in range(T)]
+    ser_p = [ctx.predict_batch(progs, t, ys[s], w.t_new) for s in range(T)]
+    serial_s = time.perf_counter() - t0
+    ctx.set_combining(True)
+    ctx.combine_stats(reset=True)
+    for _ in range(2):
+        com_l, dl = _burst(lambda s: ctx.logml_batch(progs, t, ys[s]), [(s,) for s in range(T)])
+        com_p, dp = _burst(lambda s: ctx.predict_batch(progs, t, ys[s], w.t_new), [(s,) for s in range(T)])
+    st = ctx.combine_stats(reset=True)
+    print(f"scenario clones: serial {serial_s * 1e3:.2f} ms, concurrent {(dl + dp) * 1e3:.2f} ms, {st}")
+    assert st["shared_k"] >= T          # at least one whole burst went through the shared factor
+    conds = [float(np.linalg.cond(oracle_np.cov(p, t, t, add_diag=True))) for p in progs]
+    for s in range(T):
+        assert not com_l[s][1].any() and not com_p[s][3].any()
+        for b in range(P):
+            check("shared-K group vs own call: logml", com_l[s][0][b], ser_l[s][0][b], TOL_LOGML, conds[b])
+            check("shared-K group vs own call: logml", com_p[s][2][b], ser_p[s][2][b], TOL_LOGML, conds[b])
+            check("shared-K group vs own call: mean", com_p[s][0][b], ser_p[s][0][b], TOL_PRED, conds[b])
+            check("shared-K group vs own call: covariance", com_p[s][1][b], ser_p[s][1][b], TOL_PRED, conds[b])
+    # the oracle itself on two tasks' first and last particle
+    for s in (0, T - 1):
+        for b in (0, P - 1):
+            mu_o, sg_o, lm_o, info_o = oracle_np.predict(progs[b], t, ys[s], w.t_new, True)
+            assert info_o == 0
+            check("shared-K group vs oracle: logml", com_p[s][2][b], lm_o, TOL_LOGML, conds[b])
+            check("shared-K group vs oracle: mean", com_p[s][0][b], mu_o, TOL_PRED, conds[b])
+            check("shared-K group vs oracle: covariance", com_p[s][1][b], sg_o, TOL_PRED, conds[b])
+    # batch-invariant contexts do not take this route (another path to the same numbers)
+    ctx.set_batch_invariant(True)
+    try:
+        ctx.combine_stats(reset=True)
+        _burst(lambda s: ctx.logml_batch(progs, t, ys[s]), [(s,) for s in range(T)])
+        assert ctx.combine_stats(reset=True)["shared_k"] == 0
+    finally:
+        ctx.set_batch_invariant(False)
+
+
+def test_default_mode_scenario_tasks_through_the_mirror(ctx):
+    """forecast_with_nowcasts in its default mode run as the reference runs it (one task per
+    scenario, here on T threads): the tasks' add_data! and predict_mvn calls reach the library with
+    identical particles and are served from shared factorisations."""
+    eng = autogp.HipEngine.__new__(autogp.HipEngine)
+    eng.ctx = ctx
+    n = 200
+    vals = 100.0 + 0.3 * np.arange(n) + 3.0 * np.sin(np.arange(n) / 7.0) \
+        + np.random.default_rng(6).standard_normal(n)
+    base = mc.fitted(eng, values=vals, seed=43, n_particles=6, n_mcmc=1, n_hmc=1, smc_data_proportion=0.5)
+    scen = nc.create_nowcast_data([[146.0 + 0.3 * k, 147.5 - 0.2 * k] for k in range(2 * T)],
+                                  mc.days(n, n + 2))
+    dates = mc.days(n + 2, n + 8)
+    ctx.combine_stats(reset=True)
+    a = nc.forecast_with_nowcasts(base, scen, dates, 50, lockstep=False, threads=T)
+    st = ctx.combine_stats(reset=True)
+    b = nc.forecast_with_nowcasts(base, scen, dates, 50)          # the one-call shared-K form
+    print("default mode, tasks on threads:", st)
+    assert a.shape == b.shape == (6, 50 * 2 * T) and np.isfinite(a).all()
+    assert st["shared_k"] > 0
+    # different random streams (per-task clones against one shared stream): same distribution
+    assert np.allclose(np.median(a, axis=1), np.median(b, axis=1), rtol=0.05)
