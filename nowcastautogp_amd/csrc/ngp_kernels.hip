@@ -2016,7 +2016,11 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     __shared__ DevProgram P;
     __shared__ double red[4][NGP_MAX_PARAMS + 1];
     __shared__ double cst[NN][2];
-    __shared__ double vals[NN][256];
+    // values, then adjoints, of the nodes: [node][thread] in LDS — except for trees of one or two
+    // leaves (REGS), whose shape is fixed (leaf, leaf, operator: nodes 0, 1, 2): three registers, no
+    // LDS round trip between the leaves, the operator and the adjoints of a row
+    constexpr bool REGS = NL <= 2;
+    __shared__ double vals[REGS ? 1 : NN][REGS ? 1 : 256];
     __shared__ unsigned leaf_dec[NL], bin_dec[NBIN > 0 ? NBIN : 1];
     const int item = items ? items[blockIdx.y] : (int)blockIdx.y;
     const int tile = blockIdx.x / split, sub = blockIdx.x % split;
@@ -2211,6 +2215,7 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
                     }
                 });
             }
+            double rv[3] = {0.0, 0.0, 0.0};
             // ---- forward: leaves, then binary nodes in postfix order
             static_for_down<NL - 1>([&](auto lc) {
                 constexpr int l = decltype(lc)::value;
@@ -2222,13 +2227,14 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
                     v = P.params[po + 1] + P.params[po + 2] * (t1 - P.params[po]) * (t2 - P.params[po]);
                 else if constexpr (PREFETCH) v = tv[l];
                 else v = tab[(long)f_slot(LD(l)) * R + dq];
-                vals[f_node(LD(l))][tid] = v;
+                if constexpr (REGS) rv[l] = v;
+                else vals[f_node(LD(l))][tid] = v;
             });
             static_for_down<NBIN - 1>([&](auto bc) {
                 constexpr int b = NBIN - 1 - decltype(bc)::value;       // ascending: postfix order
                 if (b >= nbin) return;
                 const int op = f_op(BD(b)), nd = f_node(BD(b));
-                const double x = vals[f_first(BD(b))][tid], y = vals[nd - 1][tid];
+                const double x = REGS ? rv[0] : vals[f_first(BD(b))][tid], y = REGS ? rv[1] : vals[nd - 1][tid];
                 double v;
                 if (op == NGP_OP_PLUS) v = x + y;
                 else if (op == NGP_OP_TIMES) v = x * y;
@@ -2239,16 +2245,22 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
                     const double g2 = PREFETCH ? sg[b][1] : sig[(long)f_slot(BD(b)) * npts + col];
                     v = g1 * kl * g2 + (1.0 - g1) * kr * (1.0 - g2);
                 }
-                vals[nd][tid] = v;
+                if constexpr (REGS) rv[2] = v;
+                else vals[nd][tid] = v;
             });
             // ---- reverse: the root's adjoint is w; adjoints overwrite values on the way down
-            vals[nops - 1][tid] = w;
+            if constexpr (REGS) {
+                if (nops == 1) rv[0] = w;
+                else rv[2] = w;
+            } else {
+                vals[nops - 1][tid] = w;
+            }
             static_for_down<NBIN - 1>([&](auto bc) {
                 constexpr int b = decltype(bc)::value;
                 if (b >= nbin) return;
                 const int op = f_op(BD(b)), nd = f_node(BD(b)), fi = f_first(BD(b));
-                const double a = vals[nd][tid];
-                const double x = vals[fi][tid], y = vals[nd - 1][tid];
+                const double a = REGS ? rv[2] : vals[nd][tid];
+                const double x = REGS ? rv[0] : vals[fi][tid], y = REGS ? rv[1] : vals[nd - 1][tid];
                 double ax, ay;   // adjoints of the first-evaluated and the second operand
                 if (op == NGP_OP_PLUS) {
                     ax = a; ay = a;
@@ -2276,14 +2288,19 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
                     ax = nat ? al_ : ar_;
                     ay = nat ? ar_ : al_;
                 }
-                vals[fi][tid] = ax;
-                vals[nd - 1][tid] = ay;
+                if constexpr (REGS) {
+                    rv[0] = ax;
+                    rv[1] = ay;
+                } else {
+                    vals[fi][tid] = ax;
+                    vals[nd - 1][tid] = ay;
+                }
             });
             static_for_down<NL - 1>([&](auto lc) {
                 constexpr int l = decltype(lc)::value;
                 if (l >= nl || !own(l)) return;
                 const int op = f_op(LD(l)), po = f_po(LD(l)), nd = f_node(LD(l));
-                const double a = vals[nd][tid];
+                const double a = REGS ? rv[l] : vals[nd][tid];
                 if (op == NGP_OP_CONSTANT) {
                     ga[l % NACC][0] += a;
                 } else if (op == NGP_OP_LINEAR) {
