@@ -2010,7 +2010,7 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
                                                                   const double *alpha,
                                                                   double *partials, int ntri,
                                                                   int split, DevSpec sp,
-                                                                  const int32_t *items) {
+                                                                  const int32_t *items, int tpw = 1) {
     constexpr int NBIN = NL - 1, NN = 2 * NL - 1;
     constexpr bool PREFETCH = NL <= 8;     // 4 NL + 2 NBIN more doubles in registers
     __shared__ DevProgram P;
@@ -2023,7 +2023,10 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     __shared__ double vals[REGS ? 1 : NN][REGS ? 1 : 256];
     __shared__ unsigned leaf_dec[NL], bin_dec[NBIN > 0 ? NBIN : 1];
     const int item = items ? items[blockIdx.y] : (int)blockIdx.y;
-    const int tile = blockIdx.x / split, sub = blockIdx.x % split;
+    // a workgroup walks `tpw` consecutive tiles of its item (large launches: the program load, the
+    // list decode and the final reduction are paid once per workgroup, a third of its life at one
+    // tile) and leaves ONE row of partial sums
+    const int tile_first = (int)(blockIdx.x / split) * tpw, sub = blockIdx.x % split;
     const int tid = threadIdx.x;
     const int nrows = 16 / split;
     load_program(&P, p.progs + item);
@@ -2065,20 +2068,12 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
         }
     }
     __syncthreads();
-    int r = 0, c = 0;
-    if constexpr (!DIAG) {
-        r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
-        while ((r + 1) * (r + 2) / 2 <= tile) ++r;
-        while (r * (r + 1) / 2 > tile) --r;
-        c = tile - r * (r + 1) / 2;
-    }
     // a wave works on ONE row at a time (its 64 lanes are 64 columns): the row index is
     // wave-uniform, which hipcc cannot see in `tid >> 6` — said explicitly, everything that is a
     // function of the row alone (t0[row], qpts[row], alpha[row], the ChangePoint sigmoid of the row)
     // becomes a scalar load instead of a vector load that every lane repeats, and the table lookups
     // of an element no longer wait behind it (they were two dependent memory round trips per row)
     const int tx = tid & 63, ty = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int col = DIAG ? 0 : c * NB + tx;
     const int np = P.n_params;
     const int nops = __builtin_amdgcn_readfirstlane(P.n_ops);
     const int nl = (nops + 1) / 2, nbin = nops / 2;       // a binary tree: nl leaves, nl - 1 binaries
@@ -2131,6 +2126,15 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     // loads that every lane repeats (the compiler barrier below forbids scalar loads: memory may
     // have changed), and the lattice coordinate stood between the row and its table lookups: two
     // dependent memory round trips per row where there is now one.
+    for (int tile = tile_first; tile < (DIAG ? tile_first + 1 : min(tile_first + tpw, ntri)); ++tile) {
+    int r = 0, c = 0;
+    if constexpr (!DIAG) {
+        r = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+        while (r * (r + 1) / 2 > tile) --r;
+        c = tile - r * (r + 1) / 2;
+    }
+    const int col = DIAG ? 0 : c * NB + tx;
     const int row0 = DIAG ? 0 : r * NB + ty * 16 + sub * nrows;
     double t1_l = 0.0, al_l = 0.0;
     int q1_l = 0;
@@ -2330,6 +2334,7 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
             if (PASS == 0 && row == col) gnoise += w;   // d K / d noise = I (w carries the 1/2)
         }
     }
+    }   // tiles of this workgroup
     // ---- deterministic reduction: wave shuffles per (node, parameter), then the four waves in order
     const int lane = tid & 63, wave = tid >> 6;
     auto wave_sum = [&](double v) {
@@ -2366,7 +2371,7 @@ __global__ __launch_bounds__(256) void grad_contract_lists_kernel(JobGeom g, Chu
     }
     __syncthreads();
     if (tid <= np) {
-        double *dst = partials + ((long)item * ntri * split + blockIdx.x) * (NGP_MAX_PARAMS + 1) + tid;
+        double *dst = partials + ((long)item * gridDim.x + blockIdx.x) * (NGP_MAX_PARAMS + 1) + tid;
         const double sum = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
         if (PASS == 0) *dst = sum;
         else *dst += sum;      // a parameter of another pass adds 0.0: its bits do not change
@@ -2854,21 +2859,27 @@ void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Ki
     }
     if (g.lattice && p.dtab) {
         const int split = grad_contract_split(ntri, Bc, g.invariant != 0);
-        nparts = ntri * split;
+        // large launches: four tiles per workgroup (not under ngp_set_batch_invariant: the grouping of
+        // a thread's partial sums would follow the batch size)
         // items sorted by tree size (grad_bucket): 1, 2, 4, 8 leaves on the register-accumulator
         // kernel, up to 16 leaves in two passes of it, larger trees on the general kernel
         const int32_t *it = items;
         int32_t whole[GRAD_BUCKETS] = {};
         whole[grad_bucket(g.maxops)] = Bc;
         const int32_t *cnt = items ? bucket_counts : whole;
+        // (... and only when every item of the chunk runs on the lists kernel: the kernel of the
+        // largest trees keeps one tile per workgroup, and a chunk has ONE partial-sum layout)
+        const int tpw = (!g.invariant && split == 1 && (long)ntri * Bc >= 65536 && cnt[GRAD_BUCKETS - 1] == 0) ? 4 : 1;
+        const int ngrp = (ntri + tpw - 1) / tpw;
+        nparts = ngrp * split;
         for (int bk = 0; bk < GRAD_BUCKETS; ++bk) {
             const int nb = cnt[bk];
             if (nb <= 0) continue;
             s = (two && (nlaunched++ & 1)) ? side : s0;
-            const dim3 grid(ntri * split, nb), blk(256);
+            const dim3 grid(ngrp * split, nb), blk(256);
 #define NGP_LAUNCH_LISTS(...)                                                                    \
     hipLaunchKernelGGL((grad_contract_lists_kernel<__VA_ARGS__>), grid, blk, 0, s, g, p, Kinv, alpha, \
-                       partials, ntri, split, sp, it)
+                       partials, ntri, split, sp, it, tpw)
             if (bk == 0) NGP_LAUNCH_LISTS(1);
             else if (bk == 1) NGP_LAUNCH_LISTS(2);
             else if (bk == 2) NGP_LAUNCH_LISTS(4);
