@@ -594,13 +594,15 @@ __global__ __launch_bounds__(256) void fill_single_kernel(JobGeom g, ChunkPtrs p
 // same order of operations per element as keval_reduced: bit-identical values.  A kernel of its own
 // (238 VGPRs would cost the single-lookup fill of stationary kernels its occupancy); `items` lists
 // the chunk's chain items (ChunkPtrs::fill_chain).
+// tpw: tiles a workgroup fills one after the other (large launches: the program is loaded and the
+// barrier paid once for `tpw` tiles; the values do not depend on it)
 __global__ __launch_bounds__(256) void fill_chain_kernel(JobGeom g, ChunkPtrs p, int ntri,
-                                                         DevSpec sp) {
+                                                         DevSpec sp, int ntiles, int tpw) {
     __shared__ DevProgram P;
     const int item = p.fill_chain[blockIdx.y] - p.fill_base;
     load_program(&P, p.progs + item);
     __syncthreads();
-    const int tile = blockIdx.x;
+    for (int tile = blockIdx.x * tpw; tile < min((int)blockIdx.x * tpw + tpw, ntiles); ++tile) {
     int r, c;
     bool aux = false;
     if (tile < ntri) {
@@ -732,6 +734,7 @@ __global__ __launch_bounds__(256) void fill_chain_kernel(JobGeom g, ChunkPtrs p,
                 *reinterpret_cast<f64x2 *>(p.auxX + ((long)item * g.naux_pad + (row - g.n0)) * g.ld + col) = v;
         }
     }
+    }   // tiles of this workgroup
 }
 
 // order[slot] = the item with the slot-th largest number of fp64 tile products since the previous
@@ -2689,9 +2692,11 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
             if (p.n_fill_other > 0)
                 hipLaunchKernelGGL(fill_lattice_kernel<false>, dim3(ntri * split_o, p.n_fill_other),
                                    dim3(256), 0, s, g, q, ntri, 0, split_o, sp);
-            if (p.n_fill_chain > 0)
-                hipLaunchKernelGGL(fill_chain_kernel, dim3(ntri, p.n_fill_chain), dim3(256), 0, s, g, q,
-                                   ntri, sp);
+            if (p.n_fill_chain > 0) {
+                const int tpw = (long)ntri * p.n_fill_chain >= 65536 ? 4 : 1;
+                hipLaunchKernelGGL(fill_chain_kernel, dim3((ntri + tpw - 1) / tpw, p.n_fill_chain), dim3(256),
+                                   0, s, g, q, ntri, sp, ntri, tpw);
+            }
             if (p.n_fill_single > 0)
                 hipLaunchKernelGGL(fill_single_kernel, dim3(ntri, p.n_fill_single), dim3(256), 0, s, g,
                                    q, ntri, sp);
@@ -2711,9 +2716,11 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
             if (p.n_fill_other > 0)
                 hipLaunchKernelGGL(fill_lattice_kernel<false>, dim3(ntiles * split, p.n_fill_other),
                                    dim3(256), 0, s, g, p, ntri, 0, split, sp);
-            if (p.n_fill_chain > 0)
-                hipLaunchKernelGGL(fill_chain_kernel, dim3(ntiles, p.n_fill_chain), dim3(256), 0, s,
-                                   g, p, ntri, sp);
+            if (p.n_fill_chain > 0) {
+                const int tpw = (long)ntiles * p.n_fill_chain >= 65536 ? 4 : 1;
+                hipLaunchKernelGGL(fill_chain_kernel, dim3((ntiles + tpw - 1) / tpw, p.n_fill_chain),
+                                   dim3(256), 0, s, g, p, ntri, sp, ntiles, tpw);
+            }
             if (p.n_fill_single > 0)
                 hipLaunchKernelGGL(fill_single_kernel,
                                    dim3(g.toep ? ntiles - ntri + g.nb0 : ntiles, p.n_fill_single),
