@@ -414,8 +414,10 @@ void       ngp_factor_destroy(ngp_factor *f);
  * reverse-mode contraction of a gradient job (grad_alpha / grad_contract* / grad_reduce),
  * 12 = the fat steps of a gradient job's general leaf (chol_col_glds_kernel<.., IDENT>: aux
  * rows [I ; y'], the sweep that also produces W = L^-T) — a different instantiation from class 0,
- * with its own flops, bytes and rate (the Toeplitz leaf of a gradient job runs class 0). */
-#define NGP_NUM_KERNEL_CLASSES 13
+ * with its own flops, bytes and rate (the Toeplitz leaf of a gradient job runs class 0),
+ * 13 = chol_small_kernel: the whole factorisation of a short series (n0 <= 256) in one launch,
+ * in place of classes 0, 1, 6, 8 and 12 (ngp_set_short_series_path). */
+#define NGP_NUM_KERNEL_CLASSES 14
 typedef struct ngp_profile {
     double   ms[NGP_NUM_KERNEL_CLASSES];       /* summed device time per class */
     int64_t  launches[NGP_NUM_KERNEL_CLASSES]; /* kernel launches per class    */
@@ -440,6 +442,18 @@ typedef struct ngp_profile {
  * qualifying items of a MIXED batch actually take it depends on the batch size unless
  * ngp_set_batch_invariant is on.  Applies to jobs staged after the call. */
 ngp_status ngp_set_structured_storage(ngp_ctx *ctx, int32_t on);
+/* Short series in one launch (on by default).  The column sweep is a chain of dependent launches
+ * per 64-wide block column; at the reference's everyday size (a few hundred points, 24-64
+ * particles: docs/vignettes/getting-started.jl:266-268) that chain is the whole call.  With this
+ * option a job whose main block is at most 256 points (value jobs: n < 320; gradient jobs:
+ * n <= 256) is factorised by ONE kernel, one workgroup per item, the matrix in registers as
+ * 16 x 16 blocks; such jobs store every tile (no structured storage) and
+ * their gradient items all take the general leaf.  The rule is the geometry's alone, so it does
+ * not make an item's bits depend on its batch.  Results agree with the column sweep to rounding
+ * (another summation order); off exists for that comparison and for A/B timing.  Resident factors
+ * (ngp_factor_*) and mixed-precision jobs stay on the column sweep.  Applies to jobs staged after
+ * the call. */
+ngp_status ngp_set_short_series_path(ngp_ctx *ctx, int32_t on);
 
 ngp_status ngp_profile_enable(ngp_ctx *ctx, int32_t on);
 ngp_status ngp_profile_reset(ngp_ctx *ctx);

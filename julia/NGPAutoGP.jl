@@ -119,6 +119,10 @@ set_combining(c::Context, on::Bool) =
 set_batch_invariant(c::Context, on::Bool) =
     check(ccall((:ngp_set_batch_invariant, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on),
           "ngp_set_batch_invariant")
+"series whose main block is at most 256 points factorised in one launch (on by default; include/ngp.h)"
+set_short_series_path(c::Context, on::Bool) =
+    check(ccall((:ngp_set_short_series_path, LIBNGP), Int32, (Ptr{Cvoid}, Int32), c.h, on),
+          "ngp_set_short_series_path")
 function combine_stats(c::Context; reset::Bool = false)
     out = zeros(Int64, 6)
     check(ccall((:ngp_combine_stats, LIBNGP), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int32), c.h, out, reset),

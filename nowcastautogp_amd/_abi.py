@@ -14,7 +14,7 @@ NGP_MAX_OPS = 64
 NGP_MAX_PARAMS = 96
 NGP_MAX_STACK = 16
 NGP_MAX_AUX = 192
-NGP_NUM_KERNEL_CLASSES = 13
+NGP_NUM_KERNEL_CLASSES = 14
 NGP_PREC_F64, NGP_PREC_MIXED = 0, 1
 NGP_INFO_NOT_REFINED = -2
 

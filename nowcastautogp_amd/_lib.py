@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("NGP_LIB") or os.path.join(_HERE, "libngp.so")  # NGP_
 
 KERNEL_CLASSES = ("chol_col", "chol_diag", "gram", "epilogue", "fill", "grad_kinv", "chol_col_thin",
                   "aux_update", "diag_ahead", "chol_col_mixed", "refine", "grad_contract",
-                  "chol_col_grad")
+                  "chol_col_grad", "chol_small")
 
 # every symbol include/ngp.h declares (tests/test_abi.py checks the library exports them all)
 SYMBOLS = (
@@ -36,7 +36,7 @@ SYMBOLS = (
     "ngp_factor_destroy", "ngp_mixture_sample", "ngp_set_structured_storage", "ngp_profile_enable", "ngp_profile_reset", "ngp_profile_get",
     "ngp_microbench_mfma_f64", "ngp_microbench_mfma_f64_detail", "ngp_microbench_hbm", "ngp_selftest_mfma_layout",
     "ngp_selftest_mfma_f32_layout", "ngp_set_combining", "ngp_combine_stats",
-    "ngp_weights_unpad_normalize", "ngp_grad_job_info", "ngp_set_batch_invariant",
+    "ngp_weights_unpad_normalize", "ngp_grad_job_info", "ngp_set_batch_invariant", "ngp_set_short_series_path",
 )
 
 
@@ -120,6 +120,7 @@ def load():
         "ngp_set_structured_storage": (i32, [vp, i32]),
         "ngp_set_combining": (i32, [vp, i32]),
         "ngp_set_batch_invariant": (i32, [vp, i32]),
+        "ngp_set_short_series_path": (i32, [vp, i32]),
         "ngp_combine_stats": (i32, [vp, C.POINTER(C.c_int64), i32]),
         "ngp_profile_enable": (i32, [vp, i32]),
         "ngp_profile_reset": (i32, [vp]),
@@ -585,6 +586,11 @@ class Context:
         """Combining of concurrent one-shot callers (include/ngp.h "concurrent callers"); on by
         default.  ``on``: False / 0 off, True / 1 on, 2 on without the bounded wait for company."""
         _chk(load().ngp_set_combining(self._h, int(on)), "ngp_set_combining")
+
+    def set_short_series_path(self, on=True):
+        """Series whose main block is at most 256 points factorised in one launch (on by default;
+        include/ngp.h ``ngp_set_short_series_path``); applies to jobs staged after the call."""
+        _chk(load().ngp_set_short_series_path(self._h, 1 if on else 0), "ngp_set_short_series_path")
 
     def set_batch_invariant(self, on=True):
         """An item's outputs no longer depend (in their last bits) on the batch it travels in

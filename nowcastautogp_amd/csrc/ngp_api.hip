@@ -302,6 +302,7 @@ struct ngp_ctx {
     bool profiling = false;
     bool toeplitz = true;   // ngp_set_structured_storage
     bool invariant = false; // ngp_set_batch_invariant (JobGeom::invariant of the jobs staged after)
+    bool short_series = true;   // ngp_set_short_series_path: n0 <= 256 factorised in one launch
     ngp_profile prof{};
     size_t mem_cap = 0;  // bytes the factor storage of one job may take
     // caching allocator: repeated jobs of the same shape (the SMC/MCMC loop, the steps of a
@@ -580,6 +581,12 @@ extern "C" ngp_status ngp_set_batch_invariant(ngp_ctx *c, int32_t on) {
     c->invariant = on != 0;
     return NGP_OK;
 }
+extern "C" ngp_status ngp_set_short_series_path(ngp_ctx *c, int32_t on) {
+    if (!c) return NGP_ERR_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->short_series = on != 0;
+    return NGP_OK;
+}
 extern "C" ngp_status ngp_profile_enable(ngp_ctx *c, int32_t on) {
     if (!c) return NGP_ERR_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -708,6 +715,18 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
     ChunkPtrs p0 = p_in;
     const bool mixed = sp != nullptr && p0.L32 != nullptr;
     hipStream_t s = ln.main;
+    // Short series: the whole sweep of an item in one launch (ngp_small_kernels.h) — a rule of the
+    // geometry alone, so an item's arithmetic does not depend on its batch.  Resident factors and the
+    // Toeplitz gradient path keep every M_j (dinv_step) and stay on the column sweep; so do chunks
+    // that fill the chip many times over, where the column sweep's matrix-core rate wins.
+    SmallPlan spl;
+    if (!mixed && dinv_step == 0 && g.short_series && small_plan(g, &spl) &&
+        (bc <= SM_MAX_ITEMS || g.invariant)) {
+        const double nn = 16.0 * spl.nbe;
+        tm.run(13, bc * small_flops(g, spl), bc * 8.0 * (nn * nn * (spl.ident ? 1.5 : 1.0) + 2.0 * g.naux * nn),
+               [&] { launch_chol_small(g, p0, bc, spl, s); });
+        return;
+    }
     // small chunks of long series: room for the split-k fat steps (chol_col_glds_kernel<.., SPLITK>);
     // the buffer stays with the context
     if (!half && bc <= AHEAD_EARLY_MAX_ITEMS && !mixed && !g.aux_identity && g.nb0 >= 8 && !g.invariant &&
@@ -940,8 +959,11 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
 
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
-    if (c->toeplitz && c->spec.precision != NGP_PREC_MIXED) g.toep = toep_stride;
     g.invariant = c->invariant ? 1 : 0;
+    g.short_series = c->short_series ? 1 : 0;
+    // (short series are factorised from registers in one launch and store every tile)
+    if (c->toeplitz && c->spec.precision != NGP_PREC_MIXED && !(g.short_series && g.nb0 <= 4))
+        g.toep = toep_stride;
     ngp_job *j = new (std::nothrow) ngp_job();
     if (!j) return NGP_ERR_TOO_LARGE;
     j->ctx = c;
@@ -1898,6 +1920,7 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
     HIPCHK(hipSetDevice(c->device));
     j->spec = c->spec;
     g.invariant = c->invariant ? 1 : 0;
+    g.short_series = c->short_series ? 1 : 0;
     // (gradient jobs store every tile: their tables are per leaf, and on a regular series the
     // stationary trees — the ones structured storage could serve — are on the Toeplitz path)
     void *q = nullptr;
@@ -2067,9 +2090,16 @@ struct LeafRun {
                                launch_aux_back(g, p, p.dinv, mstep, (double *)d_kinv, 0, bc, cc, s);
                            });
             } else {
+                SmallPlan spl;
+                const bool short_job = g.short_series && small_plan(g, &spl) &&
+                                       (bc <= SM_MAX_ITEMS || g.invariant);   // factor_chunk's rule
                 tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
-                    launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
-                                     (double *)d_quad, bc, s, ln.side, ln.fork, ln.join);
+                    if (short_job)
+                        launch_grad_kinv_small(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
+                                               (double *)d_quad, bc, s);
+                    else
+                        launch_grad_kinv(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
+                                         (double *)d_quad, bc, s, ln.side, ln.fork, ln.join);
                 });
             }
             // the chunk's items sorted by tree size: every size class runs on the contraction kernel
@@ -2279,15 +2309,18 @@ static ngp_status grad_stage_impl(ngp_ctx *c, int32_t B, const ngp_kernel *kerne
     // blocks, short enough for the weights kernel's LDS image, and a tree without Linear or
     // ChangePoint nodes
     bool regular = false;
-    bool on, invariant;
+    bool on, invariant, short_series;
     double jitter;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         on = c->toeplitz;
         invariant = c->invariant;
+        short_series = c->short_series;
         jitter = c->spec.jitter;
     }
-    if (on && n >= 2 * NB && n <= 8192) {
+    // (series of up to 256 points: the general leaf factorises them in one launch,
+    // ngp_small_kernels.h — shorter than the Toeplitz leaf's chain of sweeps)
+    if (on && n >= 2 * NB && n <= 8192 && !(short_series && n <= 4 * NB)) {
         std::vector<double> real(t, t + n);
         std::vector<int32_t> q;
         double hh = 0.0;

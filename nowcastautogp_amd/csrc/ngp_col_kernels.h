@@ -24,6 +24,9 @@ struct NoProbe {
     // record the wave's stamps if block column j is the one being watched
     __device__ __forceinline__ void emit_diag(int, int, int) {}
     __device__ __forceinline__ void emit_col(int, int, int, int, int, int, bool) {}
+    // chol_small_kernel: a wave's identity / the sweep it is in
+    __device__ __forceinline__ void begin(int, int, int) {}
+    __device__ __forceinline__ void sweep(int) {}
 };
 
 // ---------------------------------------------------------------------------------------

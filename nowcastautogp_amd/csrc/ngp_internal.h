@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "../../include/ngp.h"
 
 namespace ngp {
@@ -106,6 +108,8 @@ struct JobGeom {
                        // the size of the batch it travels in (no split-k of small chunks, gradient
                        // routing and contraction shapes by item / geometry only, the epilogue never
                        // on the resident tables of a single-chunk job)
+    int32_t short_series;  // ngp_set_short_series_path: n0 <= 256 is factorised in one launch
+    int32_t pad_;
     double  h;         // lattice step
     int64_t ld;        // row stride of the factor storage (= n0)
     int64_t item_stride;  // elements per item in the factor storage
@@ -163,6 +167,93 @@ struct EpiPtrs {
     const double *tab, *sig;  // [B][maxstat][R], [B][maxcp][npts]
     const int32_t *qpts;      // [npts]
 };
+
+// ---- short series in one launch (ngp_small_kernels.h) ------------------------------------
+constexpr int SM_WAVES = 8, SM_THREADS = 64 * SM_WAVES;   // two waves per SIMD: 256 VGPRs each
+constexpr int SM_NSLOT = 20;           // register blocks per wave (8 VGPRs each)
+constexpr int SM_DSTR = 17;            // row stride of a diagonal block in LDS (doubles)
+constexpr int SM_MAX_PANEL = 34;       // panel blocks of one step: main rows + the sweep's aux row-blocks
+constexpr int SM_MAX_SWEEPS = 4;
+constexpr int SM_MAX_ITEMS = 2048;     // larger chunks fill the chip on the column sweep
+
+// One sweep over the block columns.  Aux row-blocks taken along: identity rows [i0, i1) (gradient
+// jobs: row-block a is e_(16a..16a+15)', it joins at column a and stays upper triangular) and dense
+// rows [a0, a1) (slab rows n0 + 16 a ...).
+struct SmallSweep {
+    int32_t main;          // 1: factorise the main block; 0: aux rows only, against the stored factor
+    int32_t i0, i1, a0, a1;
+};
+struct SmallPlan {
+    int32_t nbe;           // 16-blocks of the main block that hold data: ceil(n_real / 16)
+    int32_t nsweeps;
+    int32_t ident;         // gradient job (aux rows [I ; y'])
+    int32_t npanel;        // panel blocks to reserve in LDS
+    SmallSweep sw[SM_MAX_SWEEPS];
+};
+
+constexpr int SM_LDS_FIXED = 8 * (16 * 256 + 16 * 16 * SM_DSTR + 256 + 16 + 256 + 32);
+inline int small_lds_bytes(const SmallPlan &pl) { return SM_LDS_FIXED + pl.npanel * 2048; }
+
+// The plan of a geometry, or false when the column sweep has to do it (n0 > 256, structured
+// storage, the Toeplitz gradient path, more aux rows than four sweeps hold).
+inline bool small_plan(const JobGeom &g, SmallPlan *pl) {
+    if (g.n0 <= 0 || g.nb0 > 4 || g.aux_e1 || g.toep) return false;
+    const int nb16 = g.n0 / 16, nbe = (g.n_real + 15) / 16;
+    if (nbe < 1 || nbe > nb16) return false;
+    const int cap_main = (SM_WAVES - 1) * SM_NSLOT, cap_aux = SM_WAVES * SM_NSLOT;
+    SmallPlan p{};
+    p.nbe = nbe;
+    p.ident = g.aux_identity ? 1 : 0;
+    int used = nbe * (nbe - 1) / 2;
+    if (used > cap_main) return false;
+    int ns = 0, npanel = nbe;
+    if (g.aux_identity) {
+        const int ytile = nb16;                           // slab rows 2 n0 ...: y'
+        const int nid = nbe * (nbe + 1) / 2;
+        bool y_done = false;
+        SmallSweep s0{1, 0, 0, 0, 0};
+        if (used + nbe <= cap_main) { s0.a0 = ytile; s0.a1 = ytile + 1; y_done = true; }
+        p.sw[ns++] = s0;
+        if (nid > cap_aux) return false;
+        SmallSweep s1{0, 0, nbe, 0, 0};
+        if (!y_done && nid + nbe <= cap_aux) { s1.a0 = ytile; s1.a1 = ytile + 1; y_done = true; }
+        p.sw[ns++] = s1;
+        npanel = std::max(npanel, nbe + nbe + 1);
+        if (!y_done) p.sw[ns++] = SmallSweep{0, 0, 0, ytile, ytile + 1};
+    } else {
+        const int nba = (g.naux + 15) / 16;
+        int a = std::min(nba, (cap_main - used) / nbe);
+        a = std::min(a, SM_MAX_PANEL - nbe);
+        p.sw[ns++] = SmallSweep{1, 0, 0, 0, a};
+        npanel = std::max(npanel, nbe + a);
+        while (a < nba) {
+            if (ns == SM_MAX_SWEEPS) return false;
+            const int b = std::min(nba, a + std::min(cap_aux / nbe, SM_MAX_PANEL - nbe));
+            p.sw[ns++] = SmallSweep{0, 0, 0, a, b};
+            npanel = std::max(npanel, nbe + b - a);
+            a = b;
+        }
+    }
+    if (npanel > SM_MAX_PANEL) return false;
+    p.nsweeps = ns;
+    p.npanel = npanel;
+    *pl = p;
+    return true;
+}
+
+// flops the launch executes per item (factor + the aux rows' solves and updates), for the profile
+inline double small_flops(const JobGeom &g, const SmallPlan &pl) {
+    const double n = 16.0 * pl.nbe;
+    double f = n * n * n / 3.0;
+    if (pl.ident) f += n * n * n / 3.0 + n * n;
+    else f += (double)g.naux * n * n;
+    return f;
+}
+
+void launch_chol_small(const JobGeom &g, const ChunkPtrs &p, int Bc, const SmallPlan &pl, hipStream_t s);
+// K^-1 = W_I W_I', alpha = W_I z and z'z of a short gradient job in one launch (16 x 16 blocks)
+void launch_grad_kinv_small(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
+                            int Bc, hipStream_t s);
 
 // ---- launchers implemented in ngp_kernels.hip ------------------------------------------
 void launch_tables(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s);

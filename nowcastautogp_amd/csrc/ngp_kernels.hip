@@ -35,6 +35,7 @@
 #include "ngp_internal.h"
 #include "ngp_mfma.h"
 #include "ngp_col_kernels.h"
+#include "ngp_small_kernels.h"
 
 namespace ngp {
 
@@ -1982,12 +1983,6 @@ __global__ __launch_bounds__(256) void grad_contract_lattice_kernel(JobGeom g, C
 // launch sized for the largest tree of the batch would run all of them at its occupancy).
 // f(std::integral_constant<int, I>) for I = FROM, FROM - 1, ..., 0: an unrolled loop by construction
 // (where `#pragma unroll` is a request hipcc may decline, indices here ARE compile-time constants)
-// lane `lane`'s value of v in every lane (two v_readlane_b32; `lane` wave-uniform)
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
 
 template <int FROM, class F>
 __device__ __forceinline__ void static_for_down(F &&f) {

@@ -11,6 +11,13 @@ __device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// lane `lane`'s value of v in every lane (two v_readlane_b32; `lane` wave-uniform)
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // ---------------------------------------------------------------------------------------
 // The fast fp64 matrix path.  Measured on MI355X (profiles/r01/ubench_mfma_f64.log):
 //   v_mfma_f64_16x16x4_f64   ~100 cycles per SIMD slot (>=2 waves/SIMD)  -> 49.5 TFLOP/s ceiling

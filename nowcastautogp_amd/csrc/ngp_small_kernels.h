@@ -1,0 +1,567 @@
+// ngp_small_kernels.h — short series (n0 <= 256): the whole factorisation of an item in ONE launch.
+//
+// The column sweep of ngp_col_kernels.h is a chain of dependent launches per 64-wide block column
+// (chol_diag -> fat / thin / full step).  At the reference's everyday size — a few hundred points,
+// 24-64 particles (docs/vignettes/getting-started.jl:266-268) — that chain IS the call: 13-14
+// launches of 5-58 us, most of them a handful of workgroups.  Here one
+// 1,024-thread workgroup per item keeps the matrix in REGISTERS as 16 x 16 blocks in the
+// v_mfma_f64_16x16x4 C/D layout and sweeps it right-looking, 16 pivots per step:
+//
+//   wave 0 ("pivot wave")  owns nothing but the diagonal blocks' critical path: it applies the last
+//            rank-16 update to diagonal block j+1, factors it (one row per lane, pivots and
+//            multipliers broadcast by v_readlane — no barrier inside a block), inverts it and
+//            posts M = L_jj^-1 in MFMA operand order — all of it while the other waves run the
+//            trailing update of step j;
+//   waves 1..15 ("workers") own the blocks below the diagonal and the aux rows, round-robin over a
+//            column-major enumeration (the blocks still active at step j are a suffix of it, so
+//            every step is balanced to one block).  A block is held TRANSPOSED, T = (A_ik)': in the
+//            C/D layout lane (r, q), register s is T[4s+q][r] = A_ik[r][4s+q] — which is at once
+//            the B operand of the solve  X' = M C'  (no LDS round trip, ngp_kernels.hip header)
+//            and, written to LDS as it stands, the A and the B operand of every trailing update
+//            (A_ik)' -= L_kj L_ij' (contiguous, conflict-free ds_read_b64 for both).
+//   The diagonal blocks live in LDS (row stride 17); the ones not next in line are updated by the
+//   workers, one block each per step.
+//
+// Two barriers per step; the step's critical path is the pivot wave's 16 x 16 factorisation +
+// inverse (~2 us), not a launch.  Aux rows that do not fit the register file beside the main block
+// (gradient jobs: the identity rows that become W_I = L^-T) are swept afterwards in the same launch
+// against the finished factor (its panels come back from L2 one step ahead, the M_j are still in
+// LDS), on all 16 waves.
+//
+// The slab layout (ngp_kernels.hip header), logdet, info and the aux rows W = X L^-T are exactly
+// what the column sweep leaves, so everything downstream (gram / epilogue, K^-1, the contraction)
+// is unchanged.  Results differ from the column sweep in the last bits (other summation order);
+// an item's bits do not depend on the batch it travels in.
+#pragma once
+#include <atomic>
+#include <type_traits>
+
+#include "ngp_col_kernels.h"
+
+namespace ngp {
+
+struct SmallLds {
+    double *Minv;     // [16][4][64]   M_j = L_jj^-1 in operand order: [t][m + 16 c] = M[m][4t + c]
+    double *Dg;       // [16][16 x 17] diagonal blocks (full symmetric) until they are factored
+    double *Lrow;     // [16][16]      L_jj of the block being inverted
+    double *rdg;      // [16]          reciprocals of its diagonal
+    double *diagL;    // [256]         diag(L), for logdet
+    int    *colstart; // [17]          first enumeration index of every block column of the sweep
+    int    *bad;      // first failed pivot + 1
+    double *Panel;    // [npanel][4][64] the finished blocks of column j, operand order
+};
+
+// f(std::integral_constant<int, I>) for I = FROM .. TO - 1: unrolled by construction (the DPP
+// controls below are instruction immediates)
+template <int FROM, int TO, class F>
+__device__ __forceinline__ void static_for_up(F &&f) {
+    if constexpr (FROM < TO) {
+        f(std::integral_constant<int, FROM>{});
+        static_for_up<FROM + 1, TO>(f);
+    }
+}
+// lane N of every 16-lane row in all lanes of that row.  (A DPP source needs two wait states
+// after the VALU instruction that wrote it; inline asm is outside the compiler's hazard
+// recogniser, hence the s_nop.)
+template <int N>
+__device__ __forceinline__ double row_bcast_f64(double v) {
+    double o;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "=v"(o) : "v"(v), "n"(N));
+    return o;
+}
+// acc += (lane N of src's row) * mul
+template <int N, bool GUARD>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double src, double mul) {
+    if constexpr (GUARD)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(src), "v"(mul), "n"(N));
+}
+
+// ---- the pivot wave: diagonal block jn -----------------------------------------------------
+// (1) the rank-16 update of column jn - 1 (its panel block is in LDS), (2) one row per lane,
+// right-looking over the 16 pivots with v_readlane broadcasts — per element the operations of the
+// textbook loop a_rn -= l_rc l_nc, c ascending —, (3) L_jj to the slab and to LDS, (4) M = L_jj^-1
+// column by column (lane c: forward substitution against broadcast LDS reads), posted in operand
+// order.  Lanes 16..63 mirror lanes 0..15 and store nothing.
+template <class Probe>
+__device__ __forceinline__ void small_pivot_block(const SmallLds &L, double *S, long ld, int jn,
+                                                  bool update, int lane, int &badl, Probe &probe) {
+    const int r16 = lane & 15, q = lane >> 4;
+    double *dg = L.Dg + jn * (16 * SM_DSTR);
+    if (update) {
+        const double *pp = L.Panel + jn * 256 + lane;
+        f64x4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double v = pp[t * 64];
+            d = mfma64(v, v, d);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dg[(q + 4 * s) * SM_DSTR + r16] -= d[s];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    probe.mark(8 * jn + 1);
+    // a[]: row r16 of the block; x[]: column r16 of M = L_jj^-1 in the making (forward substitution,
+    // right-looking too: once x_c is final, L[n][c] x_c leaves every later entry — with the very
+    // L[n][c] the factorisation broadcasts, so the inverse costs one instruction per multiplier
+    // and no pass of its own).  Broadcasts are DPP row_newbcast inside the 16-lane row (the four
+    // rows of the wave mirror each other): a[n] -= l_r l_n is ONE v_fmac_f64_dpp, no SGPR traffic.
+    double a[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        a[c] = dg[r16 * SM_DSTR + c];
+        x[c] = (c == r16) ? 1.0 : 0.0;
+    }
+    double dgl = 0.0;
+    double piv = row_bcast_f64<0>(a[0]);
+    static_for_up<0, 16>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        double dk, ri;
+        sqrt_and_rcp(piv, dk, ri);
+        if (!(piv > 0.0) && badl == 0) badl = 16 * jn + c + 1;
+        const double l = (r16 == c) ? dk : a[c] * ri;
+        a[c] = (r16 >= c) ? l : 0.0;
+        dgl = (r16 == c) ? dk : dgl;
+        const double xc = x[c] * ri;
+        x[c] = xc;
+        const double nl = -l, nxc = -xc;
+        if constexpr (c + 1 < 16) {
+            // column c + 1 first: the next pivot is then on its way while the rest is applied
+            fmac_row_bcast<c + 1, true>(a[c + 1], l, nl);
+            piv = row_bcast_f64<c + 1>(a[c + 1]);
+            fmac_row_bcast<c + 1, false>(x[c + 1], l, nxc);
+            static_for_up<c + 2, 16>([&](auto nn) {
+                constexpr int n = decltype(nn)::value;
+                fmac_row_bcast<n, false>(a[n], l, nl);
+                fmac_row_bcast<n, false>(x[n], l, nxc);
+            });
+        }
+    });
+    probe.mark(8 * jn + 2);
+    if (lane < 16) {
+        L.diagL[16 * jn + r16] = dgl;
+        double *dst = dg + r16 * SM_DSTR;            // L_jj takes the block's place (to the slab after the sweep)
+        double *mo = L.Minv + jn * 256 + (r16 >> 2) * 64 + 16 * (r16 & 3);
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            f64x2 w;
+            dst[c] = a[c];
+            dst[c + 1] = a[c + 1];
+            w.x = x[c];
+            w.y = x[c + 1];
+            *reinterpret_cast<f64x2 *>(mo + c) = w;
+        }
+    }
+    probe.mark(8 * jn + 3);
+}
+
+// The barrier of the sweep's steps: LDS traffic only.  __syncthreads() also waits for every global
+// access of the wave (s_waitcnt vmcnt(0)): the panel loads an aux-only sweep has in flight for the
+// NEXT step would be waited for at every barrier, and so would any store.  Inside a sweep nothing
+// one wave writes to the slab is read by another (between sweeps: __syncthreads()).
+__device__ __forceinline__ void small_bar() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// a wave-uniform value the optimiser may not look through: what is derived from it is recomputed
+// where it is used (a handful of scalar instructions) instead of being hoisted out of the sweep's
+// loop for all twenty slots at once, which spilled four hundred SGPRs
+__device__ __forceinline__ int opaque_sgpr(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+// blocks of column k in the enumeration of a sweep: main rows below the diagonal, identity
+// row-blocks that have joined (a <= k), dense aux row-blocks
+__device__ __forceinline__ int small_col_count(const SmallSweep &sw, int nbe, int k) {
+    const int cm = sw.main ? nbe - 1 - k : 0;
+    const int ci = max(min(sw.i1, k + 1) - sw.i0, 0);
+    return cm + ci + (sw.a1 - sw.a0);
+}
+
+// after a main sweep: the factored diagonal blocks (LDS, row stride 17) to the slab, one block per
+// wave and turn (every wave calls it behind the sweep's last barrier)
+__device__ __forceinline__ void small_store_diag(const SmallLds &L, double *S, long ld, int nbe,
+                                                 int lane, int wave) {
+    const int r16 = lane & 15, q = lane >> 4;
+    for (int w = wave; w < nbe; w += SM_WAVES) {
+        const double *dg = L.Dg + w * (16 * SM_DSTR) + r16 * SM_DSTR + q;
+        double *dst = S + (long)(16 * w + r16) * ld + 16 * w + q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dst[4 * t] = dg[4 * t];
+    }
+}
+
+template <bool MAIN, class Probe>
+__device__ __forceinline__ void small_sweep(const JobGeom &g, const SmallPlan &pl, const SmallSweep sw,
+                                            const SmallLds &L, double *S, int tid, int lane, int wave,
+                                            int &badl, Probe &probe) {
+    const int nbe = pl.nbe;
+    const int r16 = lane & 15, q = lane >> 4;
+    const long ld = g.ld;
+    const bool store_main = pl.nsweeps > 1;       // value jobs of one sweep: nobody reads L again
+    if (MAIN && wave == 0) {
+        // ---- the pivot wave ----
+        small_pivot_block(L, S, ld, 0, false, lane, badl, probe);
+        small_bar();
+        for (int j = 0; j < nbe; ++j) {
+            small_bar();                           // the workers' solves of column j
+            probe.mark(8 * (j + 1));
+            if (j + 1 < nbe) small_pivot_block(L, S, ld, j + 1, true, lane, badl, probe);
+            small_bar();
+            probe.mark(8 * (j + 1) + 4);
+        }
+        if (pl.nsweeps > 1) small_store_diag(L, S, ld, nbe, lane, wave);
+        return;
+    }
+
+    // ---- workers ----
+    const int nwork = MAIN ? SM_WAVES - 1 : SM_WAVES;
+    const int widx = MAIN ? wave - 1 : wave;
+    int nblk = 0;
+    for (int k = 0; k < nbe; ++k) nblk += small_col_count(sw, nbe, k);
+    const int nid = sw.i1 - sw.i0;
+    // per slot: block column (-1: none) and, packed, its panel index | slab row / 16 << 8 | the
+    // column it joins at << 16 (identity row-block a: column a — its blocks are zero before that
+    // and have no panel entry)
+    int bk[SM_NSLOT], bw[SM_NSLOT];
+    f64x4 acc[SM_NSLOT];
+    // (a wave's slots ascend through the column-major enumeration: the scan for a slot's column
+    // carries on where the previous slot's ended — in registers; a lookup of colstart[] in LDS per
+    // probe made this prologue 10 us)
+    int sk = 0, scs = 0, scnt = small_col_count(sw, nbe, 0);
+#pragma unroll
+    for (int s = 0; s < SM_NSLOT; ++s) {
+        const int idx = widx + nwork * s;
+        int k = -1, row16 = 0, pi = 0, ident = 0, adiag = 0, join = 0;
+        if (idx < nblk) {
+            while (idx >= scs + scnt) {
+                scs += scnt;
+                ++sk;
+                scnt = small_col_count(sw, nbe, sk);
+            }
+            k = sk;
+            const int rem = idx - scs;
+            const int cm = sw.main ? nbe - 1 - k : 0;
+            const int ci = max(min(sw.i1, k + 1) - sw.i0, 0);
+            if (rem < cm) {
+                row16 = k + 1 + rem;
+                pi = k + 1 + rem;
+            } else if (rem < cm + ci) {
+                const int a = sw.i0 + (rem - cm);
+                row16 = g.n0 / 16 + a;
+                pi = nbe + (a - sw.i0);
+                ident = 1;
+                adiag = (a == k) ? 1 : 0;
+                join = a;
+            } else {
+                const int a = sw.a0 + (rem - cm - ci);
+                row16 = g.n0 / 16 + a;
+                pi = nbe + nid + (a - sw.a0);
+            }
+        }
+        bk[s] = __builtin_amdgcn_readfirstlane(k);
+        bw[s] = __builtin_amdgcn_readfirstlane(pi | (row16 << 8) | (join << 16));
+        ident = __builtin_amdgcn_readfirstlane(ident);
+        adiag = __builtin_amdgcn_readfirstlane(adiag);
+        if (bk[s] >= 0 && !ident) {
+            const double *src = S + (long)(16 * ((bw[s] >> 8) & 255) + r16) * ld + 16 * bk[s] + q;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[s][t] = src[4 * t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[s][t] = (adiag && r16 == 4 * t + q) ? 1.0 : 0.0;
+        }
+    }
+    // aux-only sweeps: the main panel of a step (at most 15 blocks) comes back from the slab (L2),
+    // one step ahead, two blocks per wave
+    f64x4 pf[2];
+    if (!MAIN) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pfk = 1 + wave + SM_WAVES * u;
+            if (pfk < nbe) {
+                const double *src = S + (long)(16 * pfk + r16) * ld + q;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pf[u][t] = src[4 * t];
+            }
+        }
+    }
+    probe.mark(7);
+    if (MAIN) small_bar();                         // M_0 is posted
+    for (int j = 0; j < nbe; ++j) {
+        probe.mark(8 * (j + 1));
+        // ---- solves of column j:  X' = M_j C'
+        if (!MAIN) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pfk = j + 1 + wave + SM_WAVES * u;
+                if (pfk < nbe) {
+                    double *dst = L.Panel + pfk * 256 + lane;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dst[t * 64] = pf[u][t];
+                }
+            }
+        }
+        const double *mi = L.Minv + j * 256 + lane;
+#pragma unroll
+        for (int s = 0; s < SM_NSLOT; ++s)
+            if (bk[s] == j) {
+                f64x4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d = mfma64(mi[t * 64], acc[s][t], d);
+                acc[s] = d;
+                const int w = opaque_sgpr(bw[s]);
+                double *dst = L.Panel + (w & 255) * 256 + lane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dst[t * 64] = d[t];
+                // to the slab in the background (the steps' barriers do not wait for stores): aux
+                // rows always, L itself only when a later sweep reads it back
+                if (store_main || ((w >> 8) & 255) >= g.n0 / 16) {
+                    double *out = S + (long)(16 * ((w >> 8) & 255) + r16) * ld + 16 * j + q;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) out[4 * t] = d[t];
+                }
+            }
+        probe.mark(8 * (j + 1) + 1);
+        small_bar();
+        probe.mark(8 * (j + 1) + 2);
+        // ---- trailing update:  (A_ik)' -= L_kj L_ij'
+        if (!MAIN) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int pfk = j + 2 + wave + SM_WAVES * u;
+                if (pfk < nbe) {
+                    const double *src = S + (long)(16 * pfk + r16) * ld + 16 * (j + 1) + q;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pf[u][t] = src[4 * t];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SM_NSLOT; ++s)
+            if (bk[s] > j && (bw[s] >> 16) <= j) {
+                const int w = opaque_sgpr(bw[s]), k = opaque_sgpr(bk[s]);
+                const double *pa = L.Panel + k * 256 + lane;
+                const double *pb = L.Panel + (w & 255) * 256 + lane;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[s] = mfma64(-pa[t * 64], pb[t * 64], acc[s]);
+            }
+        if (MAIN) {
+            // the diagonal blocks that are not next in line, at most two per worker
+            for (int k = j + 2 + widx; k < nbe; k += nwork) {
+                const double *pp = L.Panel + k * 256 + lane;
+                f64x4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double v = pp[t * 64];
+                    d = mfma64(v, v, d);
+                }
+                double *dg = L.Dg + k * (16 * SM_DSTR);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dg[(q + 4 * s) * SM_DSTR + r16] -= d[s];
+            }
+        }
+        probe.mark(8 * (j + 1) + 3);
+        small_bar();
+    }
+    probe.mark(8 * (nbe + 1));
+    if (MAIN && store_main) small_store_diag(L, S, ld, nbe, lane, wave);
+}
+
+template <class Probe = NoProbe>
+__global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, ChunkPtrs p, SmallPlan pl) {
+    extern __shared__ double sm_lds[];
+    SmallLds L;
+    L.Minv = sm_lds;
+    L.Dg = L.Minv + 16 * 256;
+    L.Lrow = L.Dg + 16 * 16 * SM_DSTR;
+    L.rdg = L.Lrow + 256;
+    L.diagL = L.rdg + 16;
+    L.colstart = reinterpret_cast<int *>(L.diagL + 256);
+    L.bad = L.colstart + 32;
+    L.Panel = L.diagL + 256 + 32;
+    const int item = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const long ld = g.ld;
+    const int nb16 = g.n0 / 16, nbe = pl.nbe;
+    double *S = p.L + (long)item * g.item_stride;
+    Probe probe;
+    probe.begin(item, wave, lane);
+    probe.mark(150);
+
+    // L is lower triangular: the 16-blocks above the diagonal inside the diagonal 64 x 64 tiles
+    // (the fill wrote K there) become zero, as chol_diag leaves them
+    if (pl.nsweeps > 1) {
+        const int c4 = tid & 15;                          // four columns
+        for (int T = 0; T < g.nb0; ++T)
+            for (int rr = tid >> 4; rr < 64; rr += SM_THREADS / 16) {
+                if ((c4 >> 2) > (rr >> 4)) {
+                    double *dst = S + (long)(64 * T + rr) * ld + 64 * T + 4 * c4;
+                    const f64x2 z = {0.0, 0.0};
+                    *reinterpret_cast<f64x2 *>(dst) = z;
+                    *reinterpret_cast<f64x2 *>(dst + 2) = z;
+                }
+            }
+    }
+    // gradient jobs: the identity rows are not written by the fill.  Every 16-block of row-block a
+    // from the start of its diagonal 64 x 64 tile on that the sweep does not compute is e' / zero
+    if (pl.ident) {
+        const int c4 = tid & 63;                          // four columns
+        const int kb = c4 >> 2;                           // their 16-block column
+        for (int a = 0; a < nb16; ++a) {
+            const bool computed = a < nbe && kb >= a && kb < nbe;
+            if (4 * c4 < g.n0 && kb >= 4 * (a >> 2) && !computed)
+                for (int rr = tid >> 6; rr < 16; rr += SM_THREADS / 64) {
+                    const int ar = 16 * a + rr;
+                    double *dst = S + (long)(g.n0 + ar) * ld + 4 * c4;
+                    f64x2 lo, hi;
+                    lo.x = (ar == 4 * c4) ? 1.0 : 0.0;
+                    lo.y = (ar == 4 * c4 + 1) ? 1.0 : 0.0;
+                    hi.x = (ar == 4 * c4 + 2) ? 1.0 : 0.0;
+                    hi.y = (ar == 4 * c4 + 3) ? 1.0 : 0.0;
+                    *reinterpret_cast<f64x2 *>(dst) = lo;
+                    *reinterpret_cast<f64x2 *>(dst + 2) = hi;
+                }
+        }
+    }
+    if (tid == 0) *L.bad = 0;
+    // the diagonal blocks to LDS
+    for (int w = wave; w < nbe; w += SM_WAVES) {
+        const double *src = S + (long)(16 * w + r16) * ld + 16 * w + q;
+        double *dg = L.Dg + w * (16 * SM_DSTR) + r16 * SM_DSTR + q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dg[4 * t] = src[4 * t];
+    }
+    small_bar();                                   // (the initialising stores drain in the background)
+
+    int badl = 0;
+    probe.mark(151);
+    for (int si = 0; si < pl.nsweeps; ++si) {
+        if (si > 0) __syncthreads();
+        probe.sweep(si);
+        if (pl.sw[si].main) small_sweep<true>(g, pl, pl.sw[si], L, S, tid, lane, wave, badl, probe);
+        else small_sweep<false>(g, pl, pl.sw[si], L, S, tid, lane, wave, badl, probe);
+    }
+    if (wave == 0 && lane == 0 && badl) *L.bad = badl;
+    __syncthreads();
+    // logdet = sum of log diag(L) over the data rows (padding rows are identity)
+    if (wave == 0) {
+        double s = 0.0;
+        for (int i = lane; i < 16 * nbe; i += 64)
+            if (i < g.n_real) s += log(L.diagL[i]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) {
+            p.logdet[item] += s;
+            const int b = *L.bad;
+            if (b && p.info[item] == 0) p.info[item] = b;
+        }
+    }
+    probe.sweep(0);
+    probe.mark(152);
+}
+
+// ---------------------------------------------------------------------------------------
+// K^-1 = W_I W_I' and alpha = W_I z of a short gradient job (n0 <= 256), behind chol_small_kernel.
+// grad_kinv_kernel gives a whole 64 x 64 tile pair to one wave: ten waves per item at n0 = 256,
+// each a k-loop of up to 256 on one SIMD (29 us of matrix-core time), 72 us per call with the
+// alpha launch beside it.  Here a wave takes ONE 16 x 16 block (a >= b) of the data rows — up to
+// 136 waves per item, k from 16 a (W_I is upper triangular) to the end of the data columns —
+// with its operands straight from L2 in v_mfma_f64_16x16x4 operand order (lane (m, q): W[16a + m]
+// [k + q]), sixteen k-slices (64 columns) requested together.  The diagonal blocks' waves also sum
+// alpha for their sixteen rows from the A operands they hold anyway; block (0, 0)'s wave adds z'z.
+// Only what the contraction reads is written: rows and columns < n_real, col <= row.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grad_kinv_small_kernel(JobGeom g, const double *L, double *Kinv,
+                                                              double *alpha, double *quad, int nbe) {
+    const int item = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pr = blockIdx.x * 4 + wave;
+    if (pr >= nbe * (nbe + 1) / 2) return;
+    int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= pr) ++a;
+    while (a * (a + 1) / 2 > pr) --a;
+    const int b = pr - a * (a + 1) / 2;   // a >= b
+    const long ld = g.ld;
+    const int r16 = lane & 15, q = lane >> 4;
+    const double *W = L + (long)item * g.item_stride + (long)g.n0 * ld;
+    const double *z = W + (long)g.n0 * ld;
+    // a Gram product may take its k in any order as long as both operands agree: lane (m, q) reads
+    // FOUR consecutive columns (32 bytes) of its row per 16-column group — slice s of the group pairs
+    // k-lane q with column 4 q + s — so a 64-column chunk is 8 + 8 wide loads instead of 32 narrow
+    // ones (the narrow form spent the kernel in the address path: 37 us per call)
+    const double *pa = W + (long)(16 * a + r16) * ld + 4 * q;
+    const double *pb = W + (long)(16 * b + r16) * ld + 4 * q;
+    const int kend = 16 * nbe;
+    const bool diag = a == b;
+    f64x4 d0 = {0.0, 0.0, 0.0, 0.0}, d1 = {0.0, 0.0, 0.0, 0.0};
+    double al = 0.0;
+    for (int k0 = 16 * a; k0 < kend; k0 += 64) {
+        // past the data columns a group is re-read from the last valid place and multiplied by
+        // zero (uniform code, every load of the chunk in flight at once)
+        f64x4 av[4], bv[4], zv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = min(k0 + 16 * u, kend - 16);
+            av[u] = *reinterpret_cast<const f64x4 *>(pa + k);
+            bv[u] = *reinterpret_cast<const f64x4 *>(pb + k);
+            if (diag) zv[u] = *reinterpret_cast<const f64x4 *>(z + k + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool live = k0 + 16 * u < kend;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double x = live ? av[u][s] : 0.0;
+                if (s & 1) d1 = mfma64(x, bv[u][s], d1);
+                else d0 = mfma64(x, bv[u][s], d0);
+                if (diag) al = fma(x, zv[u][s], al);
+            }
+        }
+    }
+    double *Ko = Kinv + (long)item * g.n0 * g.n0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) Ko[(long)(16 * a + q + 4 * s) * g.n0 + 16 * b + r16] = d0[s] + d1[s];
+    if (diag) {
+        al += __shfl_xor(al, 16, 64);
+        al += __shfl_xor(al, 32, 64);
+        if (q == 0) alpha[(long)item * g.n0 + 16 * a + r16] = al;
+    }
+    if (pr == 0) {
+        double s = 0.0;
+        for (int i = lane; i < g.n_real; i += 64) s += z[i] * z[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) quad[item] = s;
+    }
+}
+
+void launch_grad_kinv_small(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
+                            int Bc, hipStream_t s) {
+    const int nbe = (g.n_real + 15) / 16, nblk = nbe * (nbe + 1) / 2;
+    hipLaunchKernelGGL(grad_kinv_small_kernel, dim3((nblk + 3) / 4, Bc), dim3(256), 0, s, g, L, Kinv, alpha,
+                       quad, nbe);
+}
+
+void launch_chol_small(const JobGeom &g, const ChunkPtrs &p, int Bc, const SmallPlan &pl,
+                       hipStream_t s) {
+    // more LDS than the 64 KiB a kernel gets unasked: once per process (the attribute is the kernel's)
+    static std::atomic<bool> attr_set{false};
+    if (!attr_set.load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute((const void *)chol_small_kernel<NoProbe>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SM_LDS_FIXED + SM_MAX_PANEL * 2048);
+        attr_set.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(chol_small_kernel<NoProbe>, dim3(Bc), dim3(SM_THREADS), small_lds_bytes(pl), s, g, p, pl);
+}
+
+}  // namespace ngp

@@ -21,6 +21,8 @@ def ctx():
     import __graft_entry__ as ge
     ge.build()
     c = _lib.Context(0)
+    # (short series store every tile and never reach the column sweep: this module is about the sweep)
+    c.set_short_series_path(False)
     yield c
     c.close()
 
