@@ -720,8 +720,7 @@ void factor_chunk(const Lane &ln, const JobGeom &g, const ChunkPtrs &p_in, int b
     // Toeplitz gradient path keep every M_j (dinv_step) and stay on the column sweep; so do chunks
     // that fill the chip many times over, where the column sweep's matrix-core rate wins.
     SmallPlan spl;
-    if (!mixed && dinv_step == 0 && g.short_series && small_plan(g, &spl) &&
-        (bc <= SM_MAX_ITEMS || g.invariant)) {
+    if (!mixed && dinv_step == 0 && small_job(g, bc, &spl)) {
         const double nn = 16.0 * spl.nbe;
         tm.run(13, bc * small_flops(g, spl), bc * 8.0 * (nn * nn * (spl.ident ? 1.5 : 1.0) + 2.0 * g.naux * nn),
                [&] { launch_chol_small(g, p0, bc, spl, s); });
@@ -1184,7 +1183,9 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
     hipStream_t s = c->stream;
     const DevSpec sp = dev_spec(j->spec);
     EventTimer tm(c->profiling, s);
-    if (!j->zeroed) {   // a re-run: the first one finds the zeros the staging copy brought
+    // a re-run: the first one finds the zeros the staging copy brought.  (Short jobs: chol_small_kernel
+    // writes both outright; whatever the chunk size turns out to be, it is at most the batch.)
+    if (!j->zeroed && !(g.n0 > 0 && small_job(g, g.B) && j->spec.precision != NGP_PREC_MIXED)) {
         HIPCHK(hipMemsetAsync(j->logdet, 0, sizeof(double) * (size_t)g.B, s));
         HIPCHK(hipMemsetAsync(j->info, 0, sizeof(int32_t) * (size_t)g.B, s));
     }
@@ -2037,7 +2038,8 @@ struct LeafRun {
         if (j->progs_dirty)   // new parameters for the same trees: the programs go up again, nothing else
             e = hipMemcpyAsync(d_prog, j->hp.data(), sizeof(DevProgram) * (size_t)B,
                                hipMemcpyHostToDevice, s);
-        if (e == hipSuccess && !j->fresh)   // a re-run: info | logdet are contiguous in the arena
+        // a re-run: info | logdet are contiguous in the arena (short jobs: written outright)
+        if (e == hipSuccess && !j->fresh && !small_job(g, Bc))
             e = hipMemsetAsync(d_info, 0, j->o_grad - j->o_info, s);
         if (e != hipSuccess) return (ngp_status)e;
         j->progs_dirty = false;
@@ -2090,9 +2092,7 @@ struct LeafRun {
                                launch_aux_back(g, p, p.dinv, mstep, (double *)d_kinv, 0, bc, cc, s);
                            });
             } else {
-                SmallPlan spl;
-                const bool short_job = g.short_series && small_plan(g, &spl) &&
-                                       (bc <= SM_MAX_ITEMS || g.invariant);   // factor_chunk's rule
+                const bool short_job = small_job(g, bc);   // factor_chunk's rule
                 tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
                     if (short_job)
                         launch_grad_kinv_small(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,

@@ -180,7 +180,9 @@ constexpr int SM_MAX_ITEMS = 2048;     // larger chunks fill the chip on the col
 // jobs: row-block a is e_(16a..16a+15)', it joins at column a and stays upper triangular) and dense
 // rows [a0, a1) (slab rows n0 + 16 a ...).
 struct SmallSweep {
-    int32_t main;          // 1: factorise the main block; 0: aux rows only, against the stored factor
+    int32_t main;          // 1: factorise the main block; 0: aux rows only, against the stored factor;
+                           // 2: the inverse phase of a gradient job — W_I = L^-T block column by block
+                           // column of L^-1, every column a wave's own task (SmallPlan::colwave)
     int32_t i0, i1, a0, a1;
 };
 struct SmallPlan {
@@ -188,6 +190,7 @@ struct SmallPlan {
     int32_t nsweeps;
     int32_t ident;         // gradient job (aux rows [I ; y'])
     int32_t npanel;        // panel blocks to reserve in LDS
+    uint64_t colwave;      // inverse phase: 4 bits per block column j — the wave that computes it
     SmallSweep sw[SM_MAX_SWEEPS];
 };
 
@@ -209,17 +212,23 @@ inline bool small_plan(const JobGeom &g, SmallPlan *pl) {
     int ns = 0, npanel = nbe;
     if (g.aux_identity) {
         const int ytile = nb16;                           // slab rows 2 n0 ...: y'
-        const int nid = nbe * (nbe + 1) / 2;
-        bool y_done = false;
-        SmallSweep s0{1, 0, 0, 0, 0};
-        if (used + nbe <= cap_main) { s0.a0 = ytile; s0.a1 = ytile + 1; y_done = true; }
-        p.sw[ns++] = s0;
-        if (nid > cap_aux) return false;
-        SmallSweep s1{0, 0, nbe, 0, 0};
-        if (!y_done && nid + nbe <= cap_aux) { s1.a0 = ytile; s1.a1 = ytile + 1; y_done = true; }
-        p.sw[ns++] = s1;
-        npanel = std::max(npanel, nbe + nbe + 1);
-        if (!y_done) p.sw[ns++] = SmallSweep{0, 0, 0, ytile, ytile + 1};
+        if (used + nbe > cap_main) return false;          // (120 + 16 <= 140)
+        p.sw[ns++] = SmallSweep{1, 0, 0, ytile, ytile + 1};
+        p.sw[ns++] = SmallSweep{2, 0, nbe, 0, 0};
+        npanel = std::max(npanel, nbe + 1);
+        // Block column j of L^-1 costs (nbe - j)(nbe - j - 1) / 2 block products, all on one wave.
+        // Longest first, each to the wave whose SIMD (waves w and w + 4 share one) carries least;
+        // of that SIMD's two waves the less loaded one.
+        int load[SM_WAVES] = {};
+        for (int j = 0; j < nbe; ++j) {
+            int best = 0;
+            for (int w = 1; w < SM_WAVES; ++w) {
+                const int sb = load[best % 4] + load[best % 4 + 4], sw_ = load[w % 4] + load[w % 4 + 4];
+                if (sw_ < sb || (sw_ == sb && load[w] < load[best])) best = w;
+            }
+            load[best] += (nbe - j) * (nbe - j - 1) / 2 + 1;
+            p.colwave |= (uint64_t)best << (4 * j);
+        }
     } else {
         const int nba = (g.naux + 15) / 16;
         int a = std::min(nba, (cap_main - used) / nbe);
@@ -236,9 +245,16 @@ inline bool small_plan(const JobGeom &g, SmallPlan *pl) {
     }
     if (npanel > SM_MAX_PANEL) return false;
     p.nsweeps = ns;
-    p.npanel = npanel;
+    p.npanel = std::max(npanel, 9);     // (the waves' 16 x 18 staging corners of the prologue: 8 x 2,304 B)
     *pl = p;
     return true;
+}
+
+// the rule every caller shares: the geometry qualifies and the chunk is not one that fills the chip
+// many times over (batch-invariant jobs: the geometry alone decides)
+inline bool small_job(const JobGeom &g, int Bc, SmallPlan *pl = nullptr) {
+    SmallPlan tmp;
+    return g.short_series && small_plan(g, pl ? pl : &tmp) && (Bc <= SM_MAX_ITEMS || g.invariant);
 }
 
 // flops the launch executes per item (factor + the aux rows' solves and updates), for the profile

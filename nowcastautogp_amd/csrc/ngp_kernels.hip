@@ -2672,7 +2672,18 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
     if (g.lattice) {
         const long nwg = (long)(ntiles - off) * Bc;
         const int split = nwg <= 1024 ? 4 : (nwg <= 2048 ? 2 : 1);
-        if (p.dtab && p.fill_other && !aux_only) {
+        // Short jobs are chains of launches a few microseconds long: ONE fill launch on the general
+        // kernel (reduced / full programs; the chain and single-table kernels compute the same
+        // values, operation for operation) instead of up to three per program shape plus the aux one
+        const bool one_launch = small_job(g, Bc);
+        if (one_launch && p.dtab && !aux_only) {
+            ChunkPtrs q = p;   // gradient job: main tiles only (y' comes from the observations)
+            q.fill_other = nullptr;
+            const long nwg_m = (long)ntri * Bc;
+            const int split_m = nwg_m <= 1024 ? 4 : (nwg_m <= 2048 ? 2 : 1);
+            hipLaunchKernelGGL(fill_lattice_kernel<true>, dim3(ntri * split_m, Bc), dim3(256), 0, s, g, q,
+                               ntri, 0, split_m, sp);
+        } else if (p.dtab && p.fill_other && !aux_only) {
             // Gradient jobs: the main tiles through the kernels of the value jobs — one lookup for a
             // stationary tree, chain programs decoded once per thread for sixteen elements, the
             // rest on the reduced program — reading the subtree tables behind the per-leaf ones;
@@ -2695,18 +2706,22 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
             if (p.n_fill_single > 0)
                 hipLaunchKernelGGL(fill_single_kernel, dim3(ntri, p.n_fill_single), dim3(256), 0, s, g,
                                    q, ntri, sp);
-            ChunkPtrs a = p;
-            a.fill_other = nullptr;
-            const long nwg_a = (long)(ntiles - ntri) * Bc;
-            const int split_a = nwg_a <= 1024 ? 4 : (nwg_a <= 2048 ? 2 : 1);
-            hipLaunchKernelGGL(fill_lattice_kernel<true>, dim3((ntiles - ntri) * split_a, Bc), dim3(256),
-                               0, s, g, a, ntri, ntri, split_a, sp);
+            // (short jobs: chol_small_kernel takes y' from the observations and neither it nor
+            // grad_kinv_small_kernel reads the zero blocks — one launch less in their chain)
+            if (!small_job(g, Bc)) {
+                ChunkPtrs a = p;
+                a.fill_other = nullptr;
+                const long nwg_a = (long)(ntiles - ntri) * Bc;
+                const int split_a = nwg_a <= 1024 ? 4 : (nwg_a <= 2048 ? 2 : 1);
+                hipLaunchKernelGGL(fill_lattice_kernel<true>, dim3((ntiles - ntri) * split_a, Bc), dim3(256),
+                                   0, s, g, a, ntri, ntri, split_a, sp);
+            }
         } else if (p.dtab) {
             ChunkPtrs q = p;
             q.fill_other = nullptr;
             hipLaunchKernelGGL(fill_lattice_kernel<true>, dim3((ntiles - off) * split, Bc), dim3(256),
                                0, s, g, q, ntri, off, split, sp);
-        } else if (p.fill_other && !aux_only) {
+        } else if (p.fill_other && !aux_only && !one_launch) {
             // staged value jobs: chain programs on their own kernel, the rest element by element
             if (p.n_fill_other > 0)
                 hipLaunchKernelGGL(fill_lattice_kernel<false>, dim3(ntiles * split, p.n_fill_other),

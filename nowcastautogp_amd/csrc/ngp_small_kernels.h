@@ -197,7 +197,8 @@ __device__ __forceinline__ void small_store_diag(const SmallLds &L, double *S, l
 }
 
 template <bool MAIN, class Probe>
-__device__ __forceinline__ void small_sweep(const JobGeom &g, const SmallPlan &pl, const SmallSweep sw,
+__device__ __forceinline__ void small_sweep(const JobGeom &g, const ChunkPtrs &p, int item,
+                                            const SmallPlan &pl, const SmallSweep sw,
                                             const SmallLds &L, double *S, int tid, int lane, int wave,
                                             int &badl, Probe &probe) {
     const int nbe = pl.nbe;
@@ -268,15 +269,40 @@ __device__ __forceinline__ void small_sweep(const JobGeom &g, const SmallPlan &p
         bw[s] = __builtin_amdgcn_readfirstlane(pi | (row16 << 8) | (join << 16));
         ident = __builtin_amdgcn_readfirstlane(ident);
         adiag = __builtin_amdgcn_readfirstlane(adiag);
-        if (bk[s] >= 0 && !ident) {
-            const double *src = S + (long)(16 * ((bw[s] >> 8) & 255) + r16) * ld + 16 * bk[s] + q;
+        if (bk[s] >= 0 && !ident && pl.ident && ((bw[s] >> 8) & 255) >= g.n0 / 8) {
+            // gradient jobs: the row-block that carries y' (slab rows 2 n0 ...) straight from the
+            // observations — the fill's aux launch is not run for short jobs (launch_fill)
+            const double *yv = p.y0 + (g.y_shared ? 0 : (long)item * g.n0) + 16 * bk[s] + q;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[s][t] = src[4 * t];
+            for (int t = 0; t < 4; ++t) acc[s][t] = (r16 == 0) ? yv[4 * t] : 0.0;
+        } else if (bk[s] >= 0 && !ident) {
+            // 32 bytes per lane, a whole 128-byte row per four lanes (the layout the sweep works in —
+            // lane (r, q) holds columns q, 4 + q, 8 + q, 12 + q — would be four 8-byte loads per lane
+            // over sixteen lines each: the address path, not the data, then sets the prologue's time);
+            // turned into that layout through LDS below
+            const double *src = S + (long)(16 * ((bw[s] >> 8) & 255) + (lane >> 2)) * ld + 16 * bk[s] +
+                                4 * (lane & 3);
+            acc[s] = *reinterpret_cast<const f64x4 *>(src);
+            bw[s] |= 1 << 24;
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[s][t] = (adiag && r16 == 4 * t + q) ? 1.0 : 0.0;
         }
     }
+    {
+        // the wave's own 16 x 18 corner of the (still unused) panel storage: rows as loaded in,
+        // the sweep's layout out (LDS is in order within a wave: no barrier)
+        double *scr = L.Panel + wave * (16 * 18);
+#pragma unroll
+        for (int s = 0; s < SM_NSLOT; ++s)
+            if (bw[s] >> 24) {
+                *reinterpret_cast<f64x4 *>(scr + (lane >> 2) * 18 + 4 * (lane & 3)) = acc[s];
+                const double *rd = scr + r16 * 18 + q;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[s][t] = rd[4 * t];
+            }
+    }
+    if (!MAIN) small_bar();                        // the panel storage is the steps' from here on
     // aux-only sweeps: the main panel of a step (at most 15 blocks) comes back from the slab (L2),
     // one step ahead, two blocks per wave
     f64x4 pf[2];
@@ -344,7 +370,7 @@ __device__ __forceinline__ void small_sweep(const JobGeom &g, const SmallPlan &p
         }
 #pragma unroll
         for (int s = 0; s < SM_NSLOT; ++s)
-            if (bk[s] > j && (bw[s] >> 16) <= j) {
+            if (bk[s] > j && ((bw[s] >> 16) & 255) <= j) {
                 const int w = opaque_sgpr(bw[s]), k = opaque_sgpr(bk[s]);
                 const double *pa = L.Panel + k * 256 + lane;
                 const double *pb = L.Panel + (w & 255) * 256 + lane;
@@ -373,6 +399,90 @@ __device__ __forceinline__ void small_sweep(const JobGeom &g, const SmallPlan &p
     if (MAIN && store_main) small_store_diag(L, S, ld, nbe, lane, wave);
 }
 
+// ---- the inverse phase of a gradient job: W_I = L^-T --------------------------------------
+// Block column j of W = L^-1 depends on nothing but L and the M_i:
+//     W_jj = M_j,    W_ij = -M_i sum_(k = j)^(i - 1) L_ik W_kj    (i = j + 1 ...),
+// so every column is ONE wave's task, start to end in its registers, with no barrier at all (the
+// right-looking sweep of the identity rows took two per block column and twice the time).  What the
+// slab gets is W_I block (j, i) = W_ij'.
+// Layouts.  W_kj is held with its rows permuted, register s of lane (n, q) = W_kj[4 q + s][n]: as
+// the B operand of L_ik W_kj its k-slot (s, q) then stands for column 4 q + s of L_ik — the four
+// consecutive columns lane (m, q) fetches with ONE 32-byte load from the slab — and the transposed
+// block goes out as one 32-byte store per lane.  The permutation costs nothing: the product
+// M_i (sum) delivers its rows in the order the A operand's lanes ask for M_i's rows, so lane m
+// reads row 4 (m & 3) + (m >> 2) of M_i from LDS.
+// L comes back from the slab (L2) through a ring of eight blocks requested eight products ahead.
+constexpr int SM_RING = 6;
+constexpr int sm_tri_row(int p) {   // stage ii >= 1 of product p: ii (ii - 1) / 2 <= p < ii (ii + 1) / 2
+    int ii = 1;
+    while (ii * (ii + 1) / 2 <= p) ++ii;
+    return ii;
+}
+struct SmallInvCol {
+    const double *S;       // the item's slab
+    const double *Minv;    // LDS: the M_i in operand order
+    double *Wout;          // slab row 16 j of W_I, column 0
+    long ld;
+    int j, len, nb16, lane;
+    f64x4 W[16];
+    f64x4 ring[SM_RING];
+};
+template <int P>
+__device__ __forceinline__ void small_inv_request(SmallInvCol &c) {
+    constexpr int ii = sm_tri_row(P), kk = P - ii * (ii - 1) / 2;
+    if constexpr (ii < 16)
+        if (ii < c.len) {
+            const int r16 = c.lane & 15, q = c.lane >> 4;
+            const double *src = c.S + (long)(16 * (c.j + ii) + r16) * c.ld + 16 * (c.j + kk) + 4 * q;
+            c.ring[P % SM_RING] = *reinterpret_cast<const f64x4 *>(src);
+        }
+}
+template <int II>
+__device__ __forceinline__ void small_inv_stage(SmallInvCol &c) {
+    if constexpr (II < 16) {
+        if (II >= c.len) return;
+        const int r16 = c.lane & 15, q = c.lane >> 4;
+        f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = {0.0, 0.0, 0.0, 0.0};
+        static_for_up<0, II>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value, P = II * (II - 1) / 2 + kk;
+            const f64x4 a = c.ring[P % SM_RING];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (kk & 1) s1 = mfma64(a[s], c.W[kk][s], s1);
+                else s0 = mfma64(a[s], c.W[kk][s], s0);
+            }
+            small_inv_request<P + SM_RING>(c);
+        });
+        if constexpr (II > 1) s0 += s1;
+        // W_ij = -M_i (sum), rows in the permuted order
+        const double *mi = c.Minv + (c.j + II) * 256 + 4 * (r16 & 3) + (r16 >> 2) + 16 * q;
+        f64x4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d = mfma64(-mi[t * 64], s0[t], d);
+        c.W[II] = d;
+        *reinterpret_cast<f64x4 *>(c.Wout + (long)r16 * c.ld + 16 * (c.j + II) + 4 * q) = d;
+        small_inv_stage<II + 1>(c);
+    }
+}
+__device__ __forceinline__ void small_inverse_column(const SmallLds &L, double *S, long ld, int n0, int nbe,
+                                                     int j, int lane) {
+    const int r16 = lane & 15, q = lane >> 4;
+    SmallInvCol c;
+    c.S = S;
+    c.Minv = L.Minv;
+    c.Wout = S + (long)(n0 + 16 * j) * ld;
+    c.ld = ld;
+    c.j = j;
+    c.len = nbe - j;
+    c.nb16 = n0 / 16;
+    c.lane = lane;
+    static_for_up<0, SM_RING>([&](auto pc) { small_inv_request<decltype(pc)::value>(c); });
+    // W_jj = M_j: register s of lane (n, q) = M_j[4 q + s][n] (operand order: [n >> 2][.. + 16 (n & 3)])
+    c.W[0] = *reinterpret_cast<const f64x4 *>(L.Minv + j * 256 + (r16 >> 2) * 64 + 16 * (r16 & 3) + 4 * q);
+    *reinterpret_cast<f64x4 *>(c.Wout + (long)r16 * ld + 16 * j + 4 * q) = c.W[0];
+    small_inv_stage<1>(c);
+}
+
 template <class Probe = NoProbe>
 __global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, ChunkPtrs p, SmallPlan pl) {
     extern __shared__ double sm_lds[];
@@ -396,41 +506,10 @@ __global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, Chunk
     probe.begin(item, wave, lane);
     probe.mark(150);
 
-    // L is lower triangular: the 16-blocks above the diagonal inside the diagonal 64 x 64 tiles
-    // (the fill wrote K there) become zero, as chol_diag leaves them
-    if (pl.nsweeps > 1) {
-        const int c4 = tid & 15;                          // four columns
-        for (int T = 0; T < g.nb0; ++T)
-            for (int rr = tid >> 4; rr < 64; rr += SM_THREADS / 16) {
-                if ((c4 >> 2) > (rr >> 4)) {
-                    double *dst = S + (long)(64 * T + rr) * ld + 64 * T + 4 * c4;
-                    const f64x2 z = {0.0, 0.0};
-                    *reinterpret_cast<f64x2 *>(dst) = z;
-                    *reinterpret_cast<f64x2 *>(dst + 2) = z;
-                }
-            }
-    }
-    // gradient jobs: the identity rows are not written by the fill.  Every 16-block of row-block a
-    // from the start of its diagonal 64 x 64 tile on that the sweep does not compute is e' / zero
-    if (pl.ident) {
-        const int c4 = tid & 63;                          // four columns
-        const int kb = c4 >> 2;                           // their 16-block column
-        for (int a = 0; a < nb16; ++a) {
-            const bool computed = a < nbe && kb >= a && kb < nbe;
-            if (4 * c4 < g.n0 && kb >= 4 * (a >> 2) && !computed)
-                for (int rr = tid >> 6; rr < 16; rr += SM_THREADS / 64) {
-                    const int ar = 16 * a + rr;
-                    double *dst = S + (long)(g.n0 + ar) * ld + 4 * c4;
-                    f64x2 lo, hi;
-                    lo.x = (ar == 4 * c4) ? 1.0 : 0.0;
-                    lo.y = (ar == 4 * c4 + 1) ? 1.0 : 0.0;
-                    hi.x = (ar == 4 * c4 + 2) ? 1.0 : 0.0;
-                    hi.y = (ar == 4 * c4 + 3) ? 1.0 : 0.0;
-                    *reinterpret_cast<f64x2 *>(dst) = lo;
-                    *reinterpret_cast<f64x2 *>(dst + 2) = hi;
-                }
-        }
-    }
+    // (What the launch leaves in the slab is what its consumers read: the aux rows W of a value
+    // job — gram_kernel —, of a gradient job the blocks of W_I = L^-T on and right of the block
+    // diagonal of the data rows and z' — grad_kinv_small_kernel —, and L itself only when a later
+    // sweep of this launch reads it back.  Nothing else of the column sweep's image is written.)
     if (tid == 0) *L.bad = 0;
     // the diagonal blocks to LDS
     for (int w = wave; w < nbe; w += SM_WAVES) {
@@ -446,8 +525,12 @@ __global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, Chunk
     for (int si = 0; si < pl.nsweeps; ++si) {
         if (si > 0) __syncthreads();
         probe.sweep(si);
-        if (pl.sw[si].main) small_sweep<true>(g, pl, pl.sw[si], L, S, tid, lane, wave, badl, probe);
-        else small_sweep<false>(g, pl, pl.sw[si], L, S, tid, lane, wave, badl, probe);
+        if (pl.sw[si].main == 2) {
+            for (int j = 0; j < nbe; ++j)
+                if ((int)((pl.colwave >> (4 * j)) & 15) == wave) small_inverse_column(L, S, ld, g.n0, nbe, j, lane);
+            probe.mark(8 * (nbe + 1));
+        } else if (pl.sw[si].main) small_sweep<true>(g, p, item, pl, pl.sw[si], L, S, tid, lane, wave, badl, probe);
+        else small_sweep<false>(g, p, item, pl, pl.sw[si], L, S, tid, lane, wave, badl, probe);
     }
     if (wave == 0 && lane == 0 && badl) *L.bad = badl;
     __syncthreads();
@@ -459,9 +542,10 @@ __global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, Chunk
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0) {
-            p.logdet[item] += s;
-            const int b = *L.bad;
-            if (b && p.info[item] == 0) p.info[item] = b;
+            // written, not accumulated: this launch is the whole factorisation of the item, so a
+            // re-run needs no memset of logdet | info before it (one link less in the chain)
+            p.logdet[item] = s;
+            p.info[item] = *L.bad;
         }
     }
     probe.sweep(0);

@@ -83,14 +83,19 @@ int main(int argc, char **argv) {
             // poison them so that a block the kernel forgets to write shows
             h[(size_t)(n0 + a) * n0 + c] = (grad && a < n0) ? ((a / NB == c / NB + 1) ? 0.0 : 777.0) : v;
         }
-    double *dL, *dsrc, *dlogdet; int *dinfo; unsigned long long *dst;
+    double *dL, *dsrc, *dlogdet, *dy0; int *dinfo; unsigned long long *dst;
     const size_t bytes = (size_t)g.item_stride * 8;
     CK(hipMalloc(&dL, bytes * B)); CK(hipMalloc(&dsrc, bytes)); CK(hipMalloc(&dlogdet, 8 * B)); CK(hipMalloc(&dinfo, 4 * B));
     CK(hipMalloc(&dst, 8 * 4 * 8 * 160)); CK(hipMemset(dst, 0, 8 * 4 * 8 * 160));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst)));
     CK(hipMemcpy(dsrc, h.data(), bytes, hipMemcpyHostToDevice));
+    // gradient jobs: the kernel takes y' from the observations, not from the slab
+    std::vector<double> hy((size_t)n0, 0.0);
+    if (grad) for (int c = 0; c < n0; ++c) hy[(size_t)c] = X[(size_t)n0 * n0 + c];
+    CK(hipMalloc(&dy0, 8 * (size_t)n0)); CK(hipMemcpy(dy0, hy.data(), 8 * (size_t)n0, hipMemcpyHostToDevice));
+    g.y_shared = 1;
     ChunkPtrs p{};
-    p.L = dL; p.logdet = dlogdet; p.info = dinfo;
+    p.L = dL; p.logdet = dlogdet; p.info = dinfo; p.y0 = dy0;
     CK(hipFuncSetAttribute((const void *)chol_small_kernel<SmallStamp>, hipFuncAttributeMaxDynamicSharedMemorySize,
                            SM_LDS_FIXED + SM_MAX_PANEL * 2048));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -115,7 +120,8 @@ int main(int argc, char **argv) {
         for (int r = 0; r < n0; ++r) {
             if (r < nr) ld_ref += log(Sx[(size_t)r * n0 + r]);
             for (int c = 0; c < n0; ++c)
-                if (c / NB <= r / NB) eL = std::max(eL, fabs(out[(size_t)r * n0 + c] - (c <= r ? Sx[(size_t)r * n0 + c] : 0.0)));
+                if (c / 16 <= r / 16 && r < 16 * pl.nbe)     // the 16-blocks on and below the diagonal, data rows
+                    eL = std::max(eL, fabs(out[(size_t)r * n0 + c] - (c <= r ? Sx[(size_t)r * n0 + c] : 0.0)));
         }
         // W = X S^-T by forward substitution on the host
         for (int a = 0; a < g.naux; ++a) {
@@ -125,9 +131,13 @@ int main(int argc, char **argv) {
                 for (int k = 0; k < c; ++k) v -= w[(size_t)k] * Sx[(size_t)c * n0 + k];
                 w[(size_t)c] = v / Sx[(size_t)c * n0 + c];
             }
-            const int c0 = (grad && a < n0) ? a / NB * NB : 0;     // W_I: from its diagonal 64-tile on
-            for (int c = c0; c < n0; ++c) eW = std::max(eW, fabs(out[(size_t)(n0 + a) * n0 + c] - w[(size_t)c]));
+            // W_I: what grad_kinv_small_kernel reads — data rows, from the row's own 16-block to the
+            // end of the data columns; other aux rows: the data columns
+            if (grad && a < n0 && a >= 16 * pl.nbe) continue;
+            const int c0 = (grad && a < n0) ? a / 16 * 16 : 0;
+            for (int c = c0; c < 16 * pl.nbe; ++c) eW = std::max(eW, fabs(out[(size_t)(n0 + a) * n0 + c] - w[(size_t)c]));
         }
+        if (pl.nsweeps == 1) eL = 0.0;   // (L itself is not written by a single-sweep launch)
         printf("max |L - S| %.2e   max |W - X S^-T| %.2e   logdet %.12f (host %.12f)   info %d\n", eL, eW, ldv, ld_ref, info);
     }
     std::vector<unsigned long long> st(4 * 8 * 160);

@@ -104,7 +104,9 @@ def test_concurrent_gradient_calls_share_launch_sequences(ctx, n, P):
           f"against {launches_serial} {st}")
     # (Python threads reach the library one GIL hand-over apart, so a burst may be served as two
     # groups; tests/c/threaded_consumer.c is the same pattern without an interpreter lock)
-    assert st["requests"] == T and st["sequences"] <= 3 and st["shared"] >= T - 1
+    # (and since the short-series path a 24-item call at n = 208 is over in 0.3 ms: a third group of
+    # late arrivals, one of them alone, is within what thread start-up jitter produces)
+    assert st["requests"] == T and st["sequences"] <= 3 and st["shared"] >= T - 2
     assert loop["requests"] == T * K and loop["sequences"] <= 0.4 * T * K
     # about one combined call's launches (a split batch runs two leaves), not T calls'
     assert launches_comb <= 0.6 * launches_serial, (launches_comb, launches_serial)

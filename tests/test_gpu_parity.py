@@ -170,7 +170,12 @@ def test_cached_factor_queries_match_refactorisation_and_oracle(ctx, n, lattice)
     lm0, info0 = f.logml()
     ref_lm, ref_info = ctx.logml_batch(w.programs, t, w.y)
     assert not info0.any() and not ref_info.any()
-    assert np.allclose(lm0, ref_lm, rtol=1e-12, atol=1e-9)
+    # (the resident factor is built by the column sweep, the one-shot call of a short series by
+    # chol_small_kernel: two summation orders, equal to rounding — judged like every other logml)
+    for p, prog in enumerate(w.programs):
+        cond = np.linalg.cond(oracle_np.cov(prog, t, t, True))
+        check("test_cached_factor_queries_match_refactorisation_and_oracle:logml", lm0[p], ref_lm[p],
+              1e-12, cond)
     queries = [(t_add, w.y_add, t_new), (np.zeros(0), np.zeros((1, 0)), t_new[:3]),
                (t_add[:1], w.y_add[:2, :1], t_new), (t_add, w.y_add, np.zeros(0))]
     for ta, ya, tn in queries:
