@@ -45,7 +45,7 @@ struct SmallLds {
     double *Dg;       // [16][16 x 17] diagonal blocks (full symmetric) until they are factored
     double *Lrow;     // [16][16]      L_jj of the block being inverted
     double *rdg;      // [16]          reciprocals of its diagonal
-    double *diagL;    // [256]         diag(L), for logdet
+    double *diagL;    // [256]         the pivots d = diag(L)^2, for logdet
     int    *colstart; // [17]          first enumeration index of every block column of the sweep
     int    *bad;      // first failed pivot + 1
     double *Panel;    // [npanel][4][64] the finished blocks of column j, operand order
@@ -105,52 +105,65 @@ __device__ __forceinline__ void small_pivot_block(const SmallLds &L, double *S, 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     probe.mark(8 * jn + 1);
-    // a[]: row r16 of the block; x[]: column r16 of M = L_jj^-1 in the making (forward substitution,
-    // right-looking too: once x_c is final, L[n][c] x_c leaves every later entry — with the very
-    // L[n][c] the factorisation broadcasts, so the inverse costs one instruction per multiplier
-    // and no pass of its own).  Broadcasts are DPP row_newbcast inside the 16-lane row (the four
-    // rows of the wave mirror each other): a[n] -= l_r l_n is ONE v_fmac_f64_dpp, no SGPR traffic.
+    // a[]: row r16 of the block; x[]: column r16 of the inverse in the making.  Broadcasts are DPP
+    // row_newbcast inside the 16-lane row (the four rows of the wave mirror each other):
+    // a[n] -= l_r l_n is ONE v_fmac_f64_dpp, no SGPR traffic.
+    //
+    // A wave issues in order, so the sixteen pivots are one chain of dependent operations and that
+    // chain — not the instruction count — is this wave's time (measured: giving the inverse to a
+    // second wave halved the instructions and changed nothing).  The loop therefore factors
+    // K_jj = Lu D Lu' with a UNIT lower triangular Lu: per pivot one reciprocal (v_rcp seed, two
+    // Newton steps), the multipliers a_r / d, and the update a_rn -= (a_r / d) a_n.  No square root
+    // is on the chain.  The inverse of Lu needs no division at all and rides along (once x_c is
+    // final, Lu[n][c] x_c leaves every later entry, with the multipliers just formed).  After the
+    // loop the sixteen 1 / sqrt(d) are formed side by side and M = L_jj^-1 = D^-1/2 Lu^-1 is a row
+    // scaling.  L_jj itself is needed by nobody (the solves take M, logdet takes the d).
     double a[16], x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         a[c] = dg[r16 * SM_DSTR + c];
         x[c] = (c == r16) ? 1.0 : 0.0;
     }
-    double dgl = 0.0;
+    double dsel = 1.0;                               // d of the lane's own row
     double piv = row_bcast_f64<0>(a[0]);
     static_for_up<0, 16>([&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        double dk, ri;
-        sqrt_and_rcp(piv, dk, ri);
+        double ri = __builtin_amdgcn_rcp(piv);
+        ri = fma(fma(-piv, ri, 1.0), ri, ri);
+        ri = fma(fma(-piv, ri, 1.0), ri, ri);
+        const double acol = a[c];                    // a_r[c] (the pivot itself in lane c)
+        const double lt = acol * ri, nlt = -lt;      // Lu[r][c]
         if (!(piv > 0.0) && badl == 0) badl = 16 * jn + c + 1;
-        const double l = (r16 == c) ? dk : a[c] * ri;
-        a[c] = (r16 >= c) ? l : 0.0;
-        dgl = (r16 == c) ? dk : dgl;
-        const double xc = x[c] * ri;
-        x[c] = xc;
-        const double nl = -l, nxc = -xc;
+        dsel = (r16 == c) ? piv : dsel;
         if constexpr (c + 1 < 16) {
             // column c + 1 first: the next pivot is then on its way while the rest is applied
-            fmac_row_bcast<c + 1, true>(a[c + 1], l, nl);
+            fmac_row_bcast<c + 1, true>(a[c + 1], acol, nlt);
             piv = row_bcast_f64<c + 1>(a[c + 1]);
-            fmac_row_bcast<c + 1, false>(x[c + 1], l, nxc);
+            const double nxc = -x[c];
+            fmac_row_bcast<c + 1, false>(x[c + 1], lt, nxc);
             static_for_up<c + 2, 16>([&](auto nn) {
                 constexpr int n = decltype(nn)::value;
-                fmac_row_bcast<n, false>(a[n], l, nl);
-                fmac_row_bcast<n, false>(x[n], l, nxc);
+                fmac_row_bcast<n, false>(a[n], acol, nlt);
+                fmac_row_bcast<n, false>(x[n], lt, nxc);
             });
         }
     });
+    // rows of the inverse scaled by 1 / sqrt(d_i) (lane i holds d_i)
+    {
+        double dk, rs;
+        sqrt_and_rcp(dsel, dk, rs);
+        static_for_up<0, 16>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            x[i] *= row_bcast_f64<i>(rs);
+        });
+    }
     probe.mark(8 * jn + 2);
     if (lane < 16) {
-        L.diagL[16 * jn + r16] = dgl;
-        double *dst = dg + r16 * SM_DSTR;            // L_jj takes the block's place (to the slab after the sweep)
+        L.diagL[16 * jn + r16] = dsel;               // d = diag(L)^2, for logdet
         double *mo = L.Minv + jn * 256 + (r16 >> 2) * 64 + 16 * (r16 & 3);
 #pragma unroll
         for (int c = 0; c < 16; c += 2) {
             f64x2 w;
-            dst[c] = a[c];
-            dst[c + 1] = a[c + 1];
             w.x = x[c];
             w.y = x[c + 1];
             *reinterpret_cast<f64x2 *>(mo + c) = w;
@@ -183,19 +196,6 @@ __device__ __forceinline__ int small_col_count(const SmallSweep &sw, int nbe, in
     return cm + ci + (sw.a1 - sw.a0);
 }
 
-// after a main sweep: the factored diagonal blocks (LDS, row stride 17) to the slab, one block per
-// wave and turn (every wave calls it behind the sweep's last barrier)
-__device__ __forceinline__ void small_store_diag(const SmallLds &L, double *S, long ld, int nbe,
-                                                 int lane, int wave) {
-    const int r16 = lane & 15, q = lane >> 4;
-    for (int w = wave; w < nbe; w += SM_WAVES) {
-        const double *dg = L.Dg + w * (16 * SM_DSTR) + r16 * SM_DSTR + q;
-        double *dst = S + (long)(16 * w + r16) * ld + 16 * w + q;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dst[4 * t] = dg[4 * t];
-    }
-}
-
 template <bool MAIN, class Probe>
 __device__ __forceinline__ void small_sweep(const JobGeom &g, const ChunkPtrs &p, int item,
                                             const SmallPlan &pl, const SmallSweep sw,
@@ -216,7 +216,6 @@ __device__ __forceinline__ void small_sweep(const JobGeom &g, const ChunkPtrs &p
             small_bar();
             probe.mark(8 * (j + 1) + 4);
         }
-        if (pl.nsweeps > 1) small_store_diag(L, S, ld, nbe, lane, wave);
         return;
     }
 
@@ -396,7 +395,6 @@ __device__ __forceinline__ void small_sweep(const JobGeom &g, const ChunkPtrs &p
         small_bar();
     }
     probe.mark(8 * (nbe + 1));
-    if (MAIN && store_main) small_store_diag(L, S, ld, nbe, lane, wave);
 }
 
 // ---- the inverse phase of a gradient job: W_I = L^-T --------------------------------------
@@ -510,7 +508,9 @@ __global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, Chunk
     // job — gram_kernel —, of a gradient job the blocks of W_I = L^-T on and right of the block
     // diagonal of the data rows and z' — grad_kinv_small_kernel —, and L itself only when a later
     // sweep of this launch reads it back.  Nothing else of the column sweep's image is written.)
-    if (tid == 0) *L.bad = 0;
+    if (tid == 0) {
+        *L.bad = 0;
+    }
     // the diagonal blocks to LDS
     for (int w = wave; w < nbe; w += SM_WAVES) {
         const double *src = S + (long)(16 * w + r16) * ld + 16 * w + q;
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, Chunk
     if (wave == 0) {
         double s = 0.0;
         for (int i = lane; i < 16 * nbe; i += 64)
-            if (i < g.n_real) s += log(L.diagL[i]);
+            if (i < g.n_real) s += 0.5 * log(L.diagL[i]);      // diagL holds the pivots d = diag(L)^2
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0) {
