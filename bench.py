@@ -371,6 +371,30 @@ def fit_forecast_wallclock(w, device, rank, args):
         vs = dict(n_particles=24, smc_data_proportion=0.1, n_mcmc=50, n_hmc=20)
         timed("vignette_scale_fit", lambda: nc.make_and_fit_model(datav, engine=eng, seed=11, **vs),
               settings={**vs, "n": nv, "hmc_config": dict(autogp.DEFAULT_HMC)})
+        # the calls that fit is made of, timed alone: 24 particles at n = 208, the short-series path
+        # (chol_small_kernel, include/ngp.h ngp_set_short_series_path) against the column sweep
+        from nowcastautogp_amd._abi import KernelArray
+        kav = KernelArray(wv.programs)
+        calls = {}
+        for on in (True, False, True, False):
+            eng.ctx.set_short_series_path(on)
+            for _ in range(5):
+                eng.ctx.logml_grad_flat(kav, wv.t, wv.y)
+                eng.ctx.logml_batch(wv.programs, wv.t, wv.y)
+            t0 = time.perf_counter()
+            for _ in range(200):
+                eng.ctx.logml_grad_flat(kav, wv.t, wv.y)
+            tg = (time.perf_counter() - t0) / 200
+            t0 = time.perf_counter()
+            for _ in range(200):
+                eng.ctx.logml_batch(wv.programs, wv.t, wv.y)
+            tl = (time.perf_counter() - t0) / 200
+            key = "short_series_path" if on else "column_sweep"
+            best = calls.setdefault(key, {"logml_call_us": 1e9, "logml_grad_call_us": 1e9})
+            best["logml_call_us"] = min(best["logml_call_us"], round(tl * 1e6, 1))
+            best["logml_grad_call_us"] = min(best["logml_grad_call_us"], round(tg * 1e6, 1))
+        eng.ctx.set_short_series_path(True)
+        legs["vignette_scale_fit"]["everyday_call_24_particles_n208"] = calls
     # ---- CPU prices at every size any leg touched, then every leg's estimate ----
     sizes = sorted({k[1] for raw in raws.values() for k in raw} | {n + d})
     prices, err = cpu_prices(args.config, rank, sizes)

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
@@ -22,6 +23,88 @@ using namespace ngp;
         hipError_t e__ = (expr);                                         \
         if (e__ != hipSuccess) return (ngp_status)(e__ > 0 ? e__ : 999); \
     } while (0)
+
+// ---- page-locked host memory for everything that crosses the bus ---------------------------
+// A copy to or from pageable memory is not asynchronous: the runtime waits for the stream, moves
+// the bytes through a bounce buffer of its own and only then returns (kernel trace of a 24-particle
+// call at n = 208: the result copy started 25 us after the last kernel had ended).  The staging
+// vectors of the jobs therefore live in page-locked memory, from a process-wide pool: blocks are
+// kept by size class when a vector lets go of them, because hipHostMalloc costs a hundred
+// microseconds and a fit stages ten thousand jobs.  When page-locking fails (no device, limits)
+// the block is ordinary memory and everything still works, only slower.
+namespace {
+class PinnedPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_;          // size class -> block
+    std::map<void *, std::pair<size_t, bool>> live_;   // block -> (class, page-locked)
+    size_t cached_ = 0;
+    static constexpr size_t MAX_CACHED = (size_t)256 << 20;
+    static size_t size_class(size_t n) {
+        size_t c = 4096;
+        while (c < n) c <<= 1;
+        return c;
+    }
+public:
+    void *take(size_t n) {
+        const size_t c = size_class(n);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_.find(c);
+            if (it != free_.end()) {
+                void *p = it->second;
+                free_.erase(it);
+                cached_ -= c;
+                return p;
+            }
+        }
+        void *p = nullptr;
+        bool pinned = hipHostMalloc(&p, c, hipHostMallocPortable) == hipSuccess && p;
+        if (!pinned) {
+            (void)hipGetLastError();
+            p = std::malloc(c);
+            if (!p) throw std::bad_alloc();
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        live_[p] = {c, pinned};
+        return p;
+    }
+    void give(void *p) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live_.find(p);
+        if (it == live_.end()) return;
+        const size_t c = it->second.first;
+        if (cached_ + c <= MAX_CACHED) {
+            free_.emplace(c, p);
+            cached_ += c;
+            return;
+        }
+        const bool pinned = it->second.second;
+        live_.erase(it);
+        if (pinned) (void)hipHostFree(p);
+        else std::free(p);
+    }
+    ~PinnedPool() {   // process exit: the runtime may already be gone — ordinary blocks only
+        for (auto &kv : free_) {
+            auto it = live_.find(kv.second);
+            if (it != live_.end() && !it->second.second) std::free(kv.second);
+        }
+    }
+};
+inline PinnedPool &pinned_pool() {
+    static PinnedPool *pool = new PinnedPool();   // never destroyed: vectors of static lifetime may outlive main
+    return *pool;
+}
+template <class T> struct PinnedAlloc {
+    typedef T value_type;
+    PinnedAlloc() = default;
+    template <class U> PinnedAlloc(const PinnedAlloc<U> &) {}
+    T *allocate(size_t n) { return static_cast<T *>(pinned_pool().take(n * sizeof(T))); }
+    void deallocate(T *p, size_t) { pinned_pool().give(p); }
+    template <class U> bool operator==(const PinnedAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const PinnedAlloc<U> &) const { return false; }
+};
+template <class T> using PinVec = std::vector<T, PinnedAlloc<T>>;
+}  // namespace
 
 namespace {
 struct ScopedEvent {   // destroyed on every exit path of the microbenchmarks
@@ -625,7 +708,7 @@ struct ngp_job {
     // the staging copy of the inputs (kept while small: stage_general), the result region of the
     // arena ([info | logml_base | logml_full | mu | sigma], offsets from info) and whether logdet /
     // info still hold the zeros they were staged with
-    std::vector<unsigned char> h_in, h_out;
+    PinVec<unsigned char> h_in, h_out;
     size_t out_off[5] = {}, out_bytes = 0;
     bool zeroed = false, copy_in_flight = false;
     // the spec the job was staged under: a later ngp_set_spec does not reach a staged job
@@ -1074,7 +1157,7 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     // copy); a large one is given back once the copy has left it
     if (in_bytes > STAGE_KEEP_BYTES) {
         if (hipStreamSynchronize(s) != hipSuccess) return fail(NGP_ERR_STATE);
-        std::vector<unsigned char>().swap(j->h_in);
+        PinVec<unsigned char>().swap(j->h_in);
         j->copy_in_flight = false;
     }
     *out = j;
@@ -1795,7 +1878,7 @@ struct GradLeaf {
     ngp_ctx *ctx = nullptr;
     JobGeom g{};
     int B = 0, n = 0;
-    std::vector<DevProgram> hp;            // compiled programs (device parameter order)
+    PinVec<DevProgram> hp;                 // compiled programs (device parameter order), page-locked: they go up on every run
     std::vector<std::vector<int>> perm;    // device parameter k of item i = the caller's perm[i][k]
     std::vector<int32_t> n_ops, n_params;
     // ONE device arena for everything that crosses the bus:
@@ -1806,7 +1889,7 @@ struct GradLeaf {
     // (ascending leaf indices; the fill of the main tiles runs on the value jobs' kernels)
     std::vector<int32_t> fill_single, fill_chain, fill_other;
     size_t o_fs = 0, o_fc = 0, o_fo = 0;
-    std::vector<unsigned char> h_in, h_out;   // staging copy of a small job's inputs; results
+    PinVec<unsigned char> h_in, h_out;        // staging copy of a small job's inputs; results
     bool fresh = false;                    // info / logdet still hold the zeros they were staged with
     bool progs_dirty = false;              // set_params since the last upload
     ngp_spec spec{};
@@ -1944,7 +2027,7 @@ ngp_status grad_leaf_stage(ngp_ctx *c, int32_t B, const ngp_kernel *kernels, int
             c->release(j->io);
             return NGP_ERR_STATE;
         }
-        std::vector<unsigned char>().swap(j->h_in);
+        PinVec<unsigned char>().swap(j->h_in);
     }
     *out = guard.release();
     return NGP_OK;
@@ -2145,7 +2228,7 @@ struct LeafRun {
     // after the lane is synchronised: device parameter order -> caller's order; d/d noise last
     void unpack(double *logml, double *grad, int32_t *info) {
         const int GP = NGP_MAX_PARAMS + 1;
-        if (!j->h_in.empty()) std::vector<unsigned char>().swap(j->h_in);   // the staging copy has left it
+        if (!j->h_in.empty()) PinVec<unsigned char>().swap(j->h_in);   // the staging copy has left it
         const int32_t *h_info = (const int32_t *)j->h_out.data();
         const double *h_grad = (const double *)(j->h_out.data() + (j->o_grad - j->o_info)),
                      *h_lm = (const double *)(j->h_out.data() + (j->o_logml - j->o_info));

@@ -48,6 +48,13 @@ hipError_t hipMalloc(void **p, size_t n) {
     *p = q;
     return 0;
 }
+// page-locked host memory: plain host memory here (the staging vectors of the jobs, ngp_api.hip
+// PinnedPool — reachable from its process-lifetime pool, so not a leak)
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
+    *p = malloc(n ? n : 1);
+    return *p ? 0 : 2;
+}
+hipError_t hipHostFree(void *p) { free(p); return 0; }
 hipError_t hipFree(void *p) {
     if (!p) return 0;
     {
