@@ -58,7 +58,7 @@ public:
             }
         }
         void *p = nullptr;
-        bool pinned = hipHostMalloc(&p, c, hipHostMallocPortable) == hipSuccess && p;
+        bool pinned = hipHostMalloc(&p, c, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && p;
         if (!pinned) {
             (void)hipGetLastError();
             p = std::malloc(c);
@@ -67,6 +67,11 @@ public:
         std::lock_guard<std::mutex> lk(mu);
         live_[p] = {c, pinned};
         return p;
+    }
+    bool is_pinned(const void *p) {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live_.find(const_cast<void *>(p));
+        return it != live_.end() && it->second.second;
     }
     void give(void *p) {
         std::lock_guard<std::mutex> lk(mu);
@@ -2118,7 +2123,13 @@ struct LeafRun {
                     *const d_logdet = io + j->o_logdet, *const d_grad = io + j->o_grad,
                     *const d_logml = io + j->o_logml;
         hipError_t e = hipSuccess;
-        if (j->progs_dirty)   // new parameters for the same trees: the programs go up again, nothing else
+        // new parameters for the same trees: the programs go up again, nothing else.  On a lattice the
+        // first kernel of the chain (tables_kernel) fetches them from the page-locked host copy itself
+        // and leaves the device copy for the rest — a copy ahead of the chain cost 20 us of a 24-item
+        // call's 110.
+        const bool fetch_in_kernel = j->progs_dirty && g.lattice && g.n0 > 0 &&
+                                     pinned_pool().is_pinned(j->hp.data());
+        if (j->progs_dirty && !fetch_in_kernel)
             e = hipMemcpyAsync(d_prog, j->hp.data(), sizeof(DevProgram) * (size_t)B,
                                hipMemcpyHostToDevice, s);
         // a re-run: info | logdet are contiguous in the arena (short jobs: written outright)
@@ -2133,6 +2144,7 @@ struct LeafRun {
             p.L = (double *)d_L;
             p.dinv = (double *)d_dinv;
             p.progs = (const DevProgram *)d_prog + b0;
+            p.progs_src = fetch_in_kernel ? j->hp.data() + b0 : nullptr;
             p.t0 = (const double *)d_t;
             p.taux = (const double *)d_t;
             p.y0 = (const double *)d_y + (g.y_shared ? 0 : (int64_t)b0 * g.n0);

@@ -119,6 +119,9 @@ struct ChunkPtrs {
     double       *L;      // [Bc][(n0 + naux_pad) x n0] factor + aux rows, row-major
     double       *dinv;   // [Bc][64 strips x 64 lanes] L_jj^-1 of the current step, MFMA strip order
     const DevProgram *progs;  // [Bc] (already offset to the chunk)
+    const DevProgram *progs_src;  // resident gradient jobs with new parameters: the programs in page-locked
+                              // HOST memory — tables_kernel reads them from there and leaves the device copy
+                              // (progs) for the kernels behind it, instead of a copy ahead of the chain; else null
     const double *t0;     // [n0]
     const double *taux;   // [da + m] times of the aux rows (appended then forecast)
     const double *y0;     // [Bc or 1][n0] (already offset to the chunk when per item)

@@ -215,8 +215,9 @@ __device__ double keval_stat(const DevProgram &P, const DevSpec &sp, int first, 
 __global__ __launch_bounds__(256) void tables_kernel(JobGeom g, ChunkPtrs p, DevSpec sp) {
     __shared__ DevProgram P;
     const int item = blockIdx.x;
-    load_program(&P, p.progs + item);
+    load_program(&P, (p.progs_src ? p.progs_src : p.progs) + item);
     __syncthreads();
+    if (p.progs_src) load_program(const_cast<DevProgram *>(p.progs) + item, &P);   // see ChunkPtrs::progs_src
     double *tab = p.tab + (long)item * g.maxstat * g.R;
     double *sig = p.sig + (long)item * g.maxcp * g.npts;
     // gradient jobs: dt = [slot][3][R]: e (the leaf value without its amplitude) and the two
@@ -226,61 +227,56 @@ __global__ __launch_bounds__(256) void tables_kernel(JobGeom g, ChunkPtrs p, Dev
         // one table per maximal stationary subtree of the tree (reduced program): all a value job
         // needs; a gradient job keeps them BEHIND its per-leaf tables (slot g.tab_sub on) — its fill
         // then runs on the reduced-program kernels like a value job's, the contraction on the leaves
+        // (subtree by subtree: keval_stat takes its opcodes wave-uniformly, so the lanes of a wave
+        // must be in the same subtree)
         for (int k = 0; k < P.n_tab; ++k) {
             const int first = P.tb_first[k], last = P.tb_last[k];
             for (int idx = threadIdx.x; idx < g.R; idx += 256)
                 tab[(long)(g.tab_sub + k) * g.R + idx] = keval_stat(P, sp, first, last, idx * g.h);
         }
     }
-    int pi = 0;
-    for (int i = 0; i < P.n_ops; ++i) {
-        const int op = __builtin_amdgcn_readfirstlane((int)P.ops[i]);
-        const int slot = __builtin_amdgcn_readfirstlane((int)P.slot[i]);
+    // One pass over (node, lattice distance) pairs and one over (ChangePoint, point) pairs: a short
+    // series (R of a few dozen — the early annealing steps of a fit) fills every leaf's table in ONE
+    // round of the workgroup instead of a round per leaf, each a chain of fp64 transcendentals
+    // (15 us of a 24-item call at n = 21).  Per entry the arithmetic is what it was.
+    for (int e = threadIdx.x; e < P.n_ops * g.R; e += 256) {
+        const int i = e / g.R, k = e - i * g.R;
+        const int op = P.ops[i], slot = P.slot[i], pi = P.poff[i];
         double *d0 = dt ? dt + (long)slot * 3 * g.R : nullptr;
+        if (!d0) break;   // leaf tables: gradient jobs only (value jobs tabulate whole subtrees, above)
         if (op == NGP_OP_SQEXP) {
             const double l = P.params[pi], a = P.params[pi + 1];
             const double den = sp.se_form ? l : l * l;
-            // leaf tables: gradient jobs only (value jobs tabulate whole subtrees, above)
-            for (int k = threadIdx.x; d0 && k < g.R; k += 256) {
-                const double d = k * g.h;
-                const double e = exp(-0.5 * d * d / den);
-                tab[(long)slot * g.R + k] = a * e;
-                d0[k] = e;
-            }
-            pi += 2;
+            const double d = k * g.h;
+            const double ev = exp(-0.5 * d * d / den);
+            tab[(long)slot * g.R + k] = a * ev;
+            d0[k] = ev;
         } else if (op == NGP_OP_GAMMAEXP) {
             const double l = P.params[pi], gam = P.params[pi + 1], a = P.params[pi + 2];
-            for (int k = threadIdx.x; d0 && k < g.R; k += 256) {
-                const double rr = k * g.h / l, u = pow(rr, gam), e = exp(-u);
-                tab[(long)slot * g.R + k] = a * e;
-                d0[k] = e;
-                d0[g.R + k] = e * u;                                  // -> d / d lengthscale
-                d0[2 * g.R + k] = (k > 0) ? e * u * log(rr) : 0.0;    // -> d / d gamma
-            }
-            pi += 3;
+            const double rr = k * g.h / l, u = pow(rr, gam), ev = exp(-u);
+            tab[(long)slot * g.R + k] = a * ev;
+            d0[k] = ev;
+            d0[g.R + k] = ev * u;                                  // -> d / d lengthscale
+            d0[2 * g.R + k] = (k > 0) ? ev * u * log(rr) : 0.0;    // -> d / d gamma
         } else if (op == NGP_OP_PERIODIC) {
             const double l = P.params[pi], per = P.params[pi + 1], a = P.params[pi + 2];
             const double c = sp.periodic_form ? 2.0 / l : 2.0 / (l * l);
-            for (int k = threadIdx.x; d0 && k < g.R; k += 256) {
-                const double d = k * g.h, ang = M_PI * d / per;
-                const double sn = sin(ang), e = exp(-c * sn * sn);
-                tab[(long)slot * g.R + k] = a * e;
-                d0[k] = e;
-                d0[g.R + k] = e * sn * sn;                 // -> d / d lengthscale
-                d0[2 * g.R + k] = e * sn * cos(ang) * d;   // -> d / d period
-            }
-            pi += 3;
-        } else if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
+            const double d = k * g.h, ang = M_PI * d / per;
+            const double sn = sin(ang), ev = exp(-c * sn * sn);
+            tab[(long)slot * g.R + k] = a * ev;
+            d0[k] = ev;
+            d0[g.R + k] = ev * sn * sn;                 // -> d / d lengthscale
+            d0[2 * g.R + k] = ev * sn * cos(ang) * d;   // -> d / d period
+        }
+    }
+    for (int e = threadIdx.x; e < P.n_ops * g.npts; e += 256) {
+        const int i = e / g.npts, pt = e - i * g.npts;
+        const int op = P.ops[i];
+        if (op == NGP_OP_CHANGEPOINT || op == OP_CP_SWAPPED) {
+            const int pi = P.poff[i];
             const double loc = P.params[pi], sc = P.params[pi + 1];
-            for (int pt = threadIdx.x; pt < g.npts; pt += 256) {
-                const double t = pt < g.n0 ? p.t0[pt] : p.taux[pt - g.n0];
-                sig[(long)slot * g.npts + pt] = cp_sigma(sp.cp_form, t, loc, sc);
-            }
-            pi += 2;
-        } else if (op == NGP_OP_CONSTANT) {
-            pi += 1;
-        } else if (op == NGP_OP_LINEAR) {
-            pi += 3;
+            const double t = pt < g.n0 ? p.t0[pt] : p.taux[pt - g.n0];
+            sig[(long)P.slot[i] * g.npts + pt] = cp_sigma(sp.cp_form, t, loc, sc);
         }
     }
 }
@@ -2656,7 +2652,10 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(f64x2 *dst, const f64x
 // ---------------------------------------------------------------------------------------
 void launch_tables(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s) {
     if (g.n0 == 0 || !g.lattice) return;
-    hipLaunchKernelGGL(tables_kernel, dim3(Bc), dim3(256), 0, s, g, p, sp);
+    JobGeom gt = g;
+    // short gradient jobs fill on the full program (launch_fill): no subtree tables behind the leaves'
+    if (p.dtab && small_job(g, Bc)) gt.tab_sub = 0;
+    hipLaunchKernelGGL(tables_kernel, dim3(Bc), dim3(256), 0, s, gt, p, sp);
 }
 
 void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp, hipStream_t s,

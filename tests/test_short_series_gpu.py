@@ -59,7 +59,8 @@ def _ensemble(w):
 
 # n, d (nowcast points), m (forecast dates): main block 64 ... 256, aux rows from 1 to 150
 VALUE_SHAPES = [(64, 1, 3), (70, 2, 5), (127, 1, 9), (130, 2, 7), (200, 1, 9), (208, 3, 30),
-                (255, 2, 9), (256, 1, 9), (261, 2, 7), (300, 1, 60), (319, 3, 100), (208, 1, 120)]
+                (255, 2, 9), (256, 1, 9), (261, 2, 7), (300, 1, 60), (319, 3, 100), (208, 1, 120),
+                (70, 2, 150), (130, 1, 180)]
 
 
 @pytest.mark.parametrize("n,d,m", VALUE_SHAPES)
@@ -160,3 +161,34 @@ def test_staged_jobs_rerun(ctx):
     r2 = gj.run()
     gj.close()
     assert np.array_equal(r1[0], r2[0]) and np.array_equal(r1[1], r2[1])
+
+
+@pytest.mark.parametrize("n", [100, 208, 300])
+def test_irregular_dates_and_plain_predict(ctx, n):
+    """dates off any lattice (the direct interpreter fills the slab, nothing is tabulated) and the
+    entry points without appended points (ngp_predict_batch, per-item y rows through
+    ngp_logml_batch): same kernel, other callers"""
+    w = make_workload("C2", n=n, P=5, D=1, m=6)
+    rng = np.random.Generator(np.random.PCG64(n))
+    t = np.sort(rng.uniform(0.0, 1.0, n))
+    t_new = t[-1] + 0.01 * np.arange(1, 7) ** 1.2
+    progs = _ensemble(w)
+    Y = np.stack([w.y * (1.0 - 0.02 * i) for i in range(len(progs))])
+    call = lambda: (ctx.predict_batch(progs, t, w.y, t_new), ctx.logml_batch(progs, t, Y),
+                    ctx.logml_grad_batch(progs, t, Y) if n <= 256 else None)
+    (pr_on, lm_on, gr_on), (pr_off, lm_off, gr_off) = _both(ctx, call)
+    for p, prog in enumerate(progs):
+        cond = np.linalg.cond(oracle_np.cov(prog, t, t, True))
+        mu, sg, lm, info = oracle_np.predict(prog, t, w.y, t_new)
+        assert info == 0
+        # predict_batch returns (mu, sigma, logml, info)
+        check("short series, irregular dates: mu", pr_on[0][p], mu, TOL_PRED, cond, (n, p))
+        check("short series, irregular dates: sigma", pr_on[1][p], sg, TOL_PRED, cond, (n, p))
+        check("short series, irregular dates: logml", pr_on[2][p], lm, TOL_LOGML, cond, (n, p))
+        check("short series vs column sweep: logml_base", pr_on[2][p], pr_off[2][p], TOL_LOGML, ctx=(n, p))
+        lmy, _ = oracle_np.logml(prog, t, Y[p])
+        check("short series, irregular dates: logml", lm_on[0][p], lmy, TOL_LOGML, cond, (n, p))
+        if gr_on is not None:
+            lmg, gg, info = oracle_np.logml_grad(prog, t, Y[p])
+            check("short series, irregular dates: gradient", gr_on[1][p], gg, 1e-7, cond, (n, p))
+            check("short series vs column sweep: gradient", gr_on[1][p], gr_off[1][p], 1e-9, ctx=(n, p))
