@@ -241,6 +241,20 @@ def fit_forecast_wallclock(w, device, rank, args):
     eng = TracingEngine(autogp.HipEngine(device))
     legs, raws = {}, {}
 
+    def debug_small_call(tag):
+        """NGP_BENCH_DEBUG_CALLS=1: the time of a 24-item call at n = 208 on this leg's context, after
+        each leg (a diagnostic: the everyday calls once came out 3.5 x slower inside the full run)"""
+        if not os.environ.get("NGP_BENCH_DEBUG_CALLS"):
+            return
+        wd = make_workload("C2", n=208, P=24, D=1)
+        for _ in range(3):
+            eng.ctx.logml_batch(wd.programs, wd.t, wd.y)
+        t0 = time.perf_counter()
+        for _ in range(100):
+            eng.ctx.logml_batch(wd.programs, wd.t, wd.y)
+        print(f"[debug] after {tag}: logml call {(time.perf_counter() - t0) / 100 * 1e6:.0f} us",
+              file=sys.stderr, flush=True)
+
     def timed(name, fn, profile=False, **extra):
         """profile: HIP-event timing of every launch of the leg (only for legs made of large
         calls: two events per launch are a few per cent of a latency-bound fit)"""
@@ -259,6 +273,7 @@ def fit_forecast_wallclock(w, device, rank, args):
             legs[name]["device_s_by_kernel_class"] = kern
             legs[name]["device_s"] = round(sum(v for k, v in kern.items() if k != "diag_ahead"), 3)
         raws[name] = raw
+        debug_small_call(name)
         return r
 
     # a fresh context pays once for its first allocations (and, right after the headline job gave

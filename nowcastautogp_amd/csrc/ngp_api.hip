@@ -38,7 +38,7 @@ class PinnedPool {
     std::multimap<size_t, void *> free_;          // size class -> block
     std::map<void *, std::pair<size_t, bool>> live_;   // block -> (class, page-locked)
     size_t cached_ = 0;
-    static constexpr size_t MAX_CACHED = (size_t)256 << 20;
+    static constexpr size_t MAX_CACHED = (size_t)256 << 20, MAX_PINNED_BLOCK = (size_t)8 << 20;
     static size_t size_class(size_t n) {
         size_t c = 4096;
         while (c < n) c <<= 1;
@@ -57,8 +57,11 @@ public:
                 return p;
             }
         }
+        // (page-locking is for the latency of small jobs; a large job's staging copy is a one-off whose
+        // time is its bytes, and locking hundreds of megabytes costs more than it saves)
         void *p = nullptr;
-        bool pinned = hipHostMalloc(&p, c, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && p;
+        bool pinned = c <= MAX_PINNED_BLOCK &&
+                      hipHostMalloc(&p, c, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && p;
         if (!pinned) {
             (void)hipGetLastError();
             p = std::malloc(c);
@@ -78,7 +81,9 @@ public:
         auto it = live_.find(p);
         if (it == live_.end()) return;
         const size_t c = it->second.first;
-        if (cached_ + c <= MAX_CACHED) {
+        // (small blocks are always kept: were the cache ever full of large ones, every 24-item call
+        // would page-lock and unlock its staging buffers again — 450 us per call, seen once)
+        if (c <= MAX_PINNED_BLOCK && (c <= ((size_t)256 << 10) || cached_ + c <= MAX_CACHED)) {
             free_.emplace(c, p);
             cached_ += c;
             return;
