@@ -2748,9 +2748,23 @@ void launch_fill(const JobGeom &g, const ChunkPtrs &p, int Bc, const DevSpec &sp
 // The product instantiation of the column sweep: NoProbe.  Weak, so that the diagnostic build
 // (scripts/stamps/ngp_stamps.hip, linked beside this file into its own library) can put the
 // stamping instantiation in their place; libngp.so contains these two and nothing of the probes.
+// 1: chol_diag_wave_kernel (ngp_small_kernels.h), 0: chol_diag_kernel — a process-wide switch for
+// same-box A/B runs (scripts/diag_form_ab.py), not part of the C-ABI
+static std::atomic<int> g_diag_form{1};
+constexpr int DIAG_WAVE_MAX_ITEMS = 512;
+extern "C" void ngp_debug_set_diag_form(int form) { g_diag_form.store(form); }
+
 __attribute__((weak)) void launch_chol_diag(const JobGeom &g, const ChunkPtrs &p, int Bc, int j,
                                             int k0, hipStream_t s) {
-    launch_chol_diag_t<NoProbe>(g, p, Bc, j, k0, s);
+    // Small chunks (the 24- and 64-particle calls of a fit), where the launch is on the critical path
+    // of the sweep: 42 -> 34 us at 64 items.  Large chunks keep chol_diag_kernel: there every
+    // workgroup competes for its CU with three others and what counts is its total work, of which the
+    // wave form — one wave factoring while three wait — has more (6,400 items: 376 -> 455 us per
+    // launch).  Batch-invariant jobs never switch (the two forms differ in the last bits).
+    if (g_diag_form.load(std::memory_order_relaxed) && !g.invariant && Bc <= DIAG_WAVE_MAX_ITEMS)
+        launch_chol_diag_wave(g, p, Bc, j, k0, s);
+    else
+        launch_chol_diag_t<NoProbe>(g, p, Bc, j, k0, s);
 }
 
 __attribute__((weak)) void launch_chol_col(const JobGeom &g, const ChunkPtrs &p, int Bc, int j,

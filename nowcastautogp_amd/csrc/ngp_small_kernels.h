@@ -89,7 +89,8 @@ __device__ __forceinline__ void fmac_row_bcast(double &acc, double src, double m
 // order.  Lanes 16..63 mirror lanes 0..15 and store nothing.
 template <class Probe>
 __device__ __forceinline__ void small_pivot_block(const SmallLds &L, double *S, long ld, int jn,
-                                                  bool update, int lane, int &badl, Probe &probe) {
+                                                  bool update, int lane, int &badl, Probe &probe,
+                                                  double *lout = nullptr, long ldl = 0) {
     const int r16 = lane & 15, q = lane >> 4;
     double *dg = L.Dg + jn * (16 * SM_DSTR);
     if (update) {
@@ -154,8 +155,19 @@ __device__ __forceinline__ void small_pivot_block(const SmallLds &L, double *S, 
         sqrt_and_rcp(dsel, dk, rs);
         static_for_up<0, 16>([&](auto ii) {
             constexpr int i = decltype(ii)::value;
-            x[i] *= row_bcast_f64<i>(rs);
+            const double f = row_bcast_f64<i>(rs);
+            x[i] *= f;
+            a[i] = (r16 >= i) ? a[i] * f : 0.0;      // L_jj = Lu D^1/2 (a[i] is still the unscaled column)
         });
+    }
+    if (lout && lane < 16) {                         // chol_diag_wave_kernel: the column sweep stores L_jj
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            f64x2 w;
+            w.x = a[c];
+            w.y = a[c + 1];
+            *reinterpret_cast<f64x2 *>(lout + (long)r16 * ldl + c) = w;
+        }
     }
     probe.mark(8 * jn + 2);
     if (lane < 16) {
@@ -626,6 +638,260 @@ __global__ __launch_bounds__(256) void grad_kinv_small_kernel(JobGeom g, const d
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0) quad[item] = s;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// chol_diag, second form: the 64 x 64 diagonal block of block column j of the column sweep, factored
+// and inverted the way chol_small_kernel does it — as 4 x 4 blocks of 16, wave 1 the pivot wave
+// (no barrier inside a block, DPP broadcasts, unit-factor chain), the six blocks below the
+// diagonal in the registers of the waves that staged them, two LDS-only barriers per 16 pivots;
+// M = L_jj^-1 by block columns (one wave each), written in the strip order the column kernels'
+// epilogues read.  chol_diag_kernel retires four pivots per two barriers with one active lane
+// factoring each 4 x 4 block and then runs the inverse as six dependent tile steps: 17.7 + 9 us of
+// its 38 at small batches (profiles/r04/chol_diag_phases_24_items.txt).
+// Staging (C_jj = K_jj - L_j L_j' over the pending columns) is chol_diag_kernel's, except that the
+// off-diagonal quadrant is formed TRANSPOSED (rows 0..31 x columns 32..63): a block in the C/D
+// layout is then already the transposed block the sweep works on (ngp_small_kernels.h header), so
+// every block stays in the wave that staged it.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void chol_diag_wave_kernel(JobGeom g, ChunkPtrs p, int j, int k0) {
+    __shared__ double Dg[4 * 16 * SM_DSTR];   // the four diagonal 16 x 16 blocks (full symmetric)
+    __shared__ double Minv[4 * 256];          // M_i = L_ii^-1, operand order
+    __shared__ double Pan[4 * 256];           // the solved blocks of the current block column, by row block
+    __shared__ double Lblk[6 * 256];          // all six blocks of L below the diagonal: (i, k) at i (i - 1) / 2 + k
+    __shared__ double dL[64];
+    __shared__ int misc[2];
+    const int item = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long ld = g.ld;
+    double *Lit = p.L + (long)item * g.item_stride;
+    double *Lj = Lit + (long)j * NB * ld;     // rows of block j
+    const int kmax = j * NB;
+    const int r16 = lane & 15, q = lane >> 4;
+    SmallLds L;
+    L.Minv = Minv;
+    L.Dg = Dg;
+    L.Lrow = nullptr;
+    L.rdg = nullptr;
+    L.diagL = dL;
+    L.colstart = misc;
+    L.bad = misc + 1;
+    L.Panel = Pan;
+    NoProbe probe;
+    // ---- staging.  wave 0: rows / columns 0..31; wave 3: 32..63; wave 2: rows 0..31 x columns 32..63
+    //      (the transpose of the quadrant below the diagonal); wave 1 (the pivot wave) stages nothing
+    f64x4 blk[4];                             // wave 0 / 3: [0] (lo,lo) [1] (lo,hi) [3] (hi,hi); wave 2: all four
+    const int wr = wave == 3 ? 1 : 0, wc = wave == 0 ? 0 : 1;
+    if (wave != 1) {
+        double acc4[2][2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
+        const double *pa = Lj + (long)(32 * wr + r16) * ld + 2 * q;
+        const double *pb = Lj + (long)(32 * wc + r16) * ld + 2 * q;
+        // the K tile in the D layout of the product, read from the part of the tile ON OR BELOW
+        // the diagonal (what the steps before this one keep up to date): element (M, N) with M < N
+        // is taken from (N, M)
+        double kt[2][2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int M = 32 * wr + 16 * mt + q + 4 * s, N = 32 * wc + 16 * nt + r16;
+                    kt[mt][nt][s] = Lj[(long)max(M, N) * ld + kmax + min(M, N)];
+                }
+        for (int kc = k0; kc < kmax; kc += 16) {
+            double a[2][4], b[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f64x2 alo = *reinterpret_cast<const f64x2 *>(pa + (long)u * 16 * ld + kc);
+                const f64x2 ahi = *reinterpret_cast<const f64x2 *>(pa + (long)u * 16 * ld + kc + 8);
+                const f64x2 blo = *reinterpret_cast<const f64x2 *>(pb + (long)u * 16 * ld + kc);
+                const f64x2 bhi = *reinterpret_cast<const f64x2 *>(pb + (long)u * 16 * ld + kc + 8);
+                a[u][0] = alo.x; a[u][1] = alo.y; a[u][2] = ahi.x; a[u][3] = ahi.y;
+                b[u][0] = blo.x; b[u][1] = blo.y; b[u][2] = bhi.x; b[u][3] = bhi.y;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const Rot4 br = rot4(b[nt][s]);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) mfma16_as_4(acc4[mt][nt], a[mt][s], br);
+                }
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f64x4 d = to_d16(acc4[mt][nt]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) blk[2 * mt + nt][s] = kt[mt][nt][s] - d[s];
+            }
+        if (wave != 2) {   // the two diagonal blocks of the quadrant to LDS (register s of lane (n, q): row q + 4 s, column n)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                double *dg = Dg + (2 * wr + b) * (16 * SM_DSTR);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dg[(q + 4 * s) * SM_DSTR + r16] = blk[3 * b][s];
+            }
+        }
+    }
+    if (tid == 0) misc[1] = 0;
+    // the wave's blocks below the diagonal, as (row block, column block) of the 4 x 4 grid: the C/D
+    // registers of block (k, i) ARE the transposed block (i, k) the sweep keeps
+    //   wave 0: blk[1] = (0,1) -> (1,0);  wave 3: blk[1] = (2,3) -> (3,2);
+    //   wave 2: blk[2 mt + nt] = (mt, 2 + nt) -> (2 + nt, mt)
+    int si[4], sk[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        si[b] = -1;
+        sk[b] = -1;
+    }
+    if (wave == 0) { si[1] = 1; sk[1] = 0; }
+    if (wave == 3) { si[1] = 3; sk[1] = 2; }
+    if (wave == 2) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { si[b] = 2 + (b & 1); sk[b] = b >> 1; }
+    }
+    __syncthreads();
+    int badl = 0;
+    double *Ljj = Lj + kmax;                  // the 64 x 64 tile in the slab
+    if (wave == 1) {
+        // ---- the pivot wave (its own branch: its registers are the block it factors, not blocks it holds)
+        small_pivot_block(L, Lit, ld, 0, false, lane, badl, probe, Ljj, ld);
+        small_bar();
+        for (int c = 0; c < 4; ++c) {
+            small_bar();                      // the solves of block column c
+            if (c + 1 < 4)
+                small_pivot_block(L, Lit, ld, c + 1, true, lane, badl, probe,
+                                  Ljj + (long)16 * (c + 1) * ld + 16 * (c + 1), ld);
+            small_bar();
+        }
+    } else {
+        small_bar();                          // M_0 is posted
+        for (int c = 0; c < 4; ++c) {
+            // ---- solves of block column c: X' = M_c C'
+            const double *mi = Minv + c * 256 + lane;
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (sk[b] == c) {
+                    f64x4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) d = mfma64(mi[t * 64], blk[b][t], d);
+                    blk[b] = d;
+                    double *pn = Pan + si[b] * 256 + lane;
+                    double *lb = Lblk + (si[b] * (si[b] - 1) / 2 + c) * 256 + lane;
+                    double *out = Ljj + (long)(16 * si[b] + r16) * ld + 16 * c + q;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        pn[t * 64] = d[t];
+                        lb[t * 64] = d[t];
+                        out[4 * t] = d[t];
+                    }
+                }
+            small_bar();
+            // ---- trailing update (the pivot wave is on the next diagonal block meanwhile)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (sk[b] > c) {
+                    const double *pa = Pan + sk[b] * 256 + lane, *pb = Pan + si[b] * 256 + lane;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) blk[b] = mfma64(-pa[t * 64], pb[t * 64], blk[b]);
+                }
+            // the diagonal blocks that are not next in line: (c + 2) on wave 0, (c + 3) on wave 3
+            const int kk = wave == 0 ? c + 2 : (wave == 3 ? c + 3 : 4);
+            if (kk < 4) {
+                const double *pp = Pan + kk * 256 + lane;
+                f64x4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double v = pp[t * 64];
+                    d = mfma64(v, v, d);
+                }
+                double *dg = Dg + kk * (16 * SM_DSTR);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dg[(q + 4 * s) * SM_DSTR + r16] -= d[s];
+            }
+            small_bar();
+        }
+    }
+    // ---- M = L_jj^-1 by block columns, wave w the column w:  W_ww = M_w,
+    //      W_iw = -M_i sum_(k = w)^(i - 1) L_ik W_kw;  out in strip order (chol_diag_kernel):
+    //      element (R, C) at  ((R >> 2) * 4 + (C >> 4)) * 64 + (R & 3) + 4 ((C & 15) >> 2) + 16 (C & 3)
+    {
+        double *dv = p.dinv + (long)item * (NB * NB);
+        auto put = [&](int bi, int bj, const f64x4 &d) {   // register s of lane (n, q): row q + 4 s, column n
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int R = 16 * bi + q + 4 * s;
+                dv[((R >> 2) * 4 + bj) * 64 + (R & 3) + 4 * (r16 >> 2) + 16 * (r16 & 3)] = d[s];
+            }
+        };
+        const int w = wave;
+        f64x4 W[4];
+        {
+            const double *mo = Minv + w * 256 + (r16 >> 2) * 64 + 16 * (r16 & 3) + q;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) W[0][s] = mo[4 * s];
+        }
+        put(w, w, W[0]);
+        const f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+        for (int bi = 0; bi < w; ++bi) put(bi, w, zero);     // the blocks above the diagonal in this column
+#pragma unroll
+        for (int ii = 1; ii < 4; ++ii) {
+            const int i = w + ii;
+            if (i < 4) {
+                f64x4 sacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < ii; ++kk) {
+                    const double *la = Lblk + (i * (i - 1) / 2 + (w + kk)) * 256 + lane;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) sacc = mfma64(la[t * 64], W[kk][t], sacc);
+                }
+                const double *mi = Minv + i * 256 + lane;
+                f64x4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d = mfma64(-mi[t * 64], sacc[t], d);
+                W[ii] = d;
+                put(i, w, d);
+            }
+        }
+    }
+    // the 16-blocks above the diagonal of L_jj are zero (the diagonal blocks' own upper parts are
+    // written with them by the pivot wave)
+    {
+        const int c4 = tid & 15, rr = tid >> 4;          // four columns, sixteen row classes
+        for (int row = rr; row < 64; row += 16)
+            if ((c4 >> 2) > (row >> 4)) {
+                double *dst = Ljj + (long)row * ld + 4 * c4;
+                const f64x2 z = {0.0, 0.0};
+                *reinterpret_cast<f64x2 *>(dst) = z;
+                *reinterpret_cast<f64x2 *>(dst + 2) = z;
+            }
+    }
+    if (wave == 1 && lane == 0 && badl) misc[1] = badl;
+    __syncthreads();
+    if (wave == 0) {
+        double sl = 0.5 * log(dL[lane]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sl += __shfl_down(sl, off, 64);
+        if (lane == 0) {
+            p.logdet[item] += sl;
+            const int b = misc[1];
+            if (b && p.info[item] == 0) p.info[item] = kmax + b;
+        }
+    }
+}
+
+void launch_chol_diag_wave(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, int k0, hipStream_t s) {
+    hipLaunchKernelGGL(chol_diag_wave_kernel, dim3(Bc), dim3(256), 0, s, g, p, j, k0);
 }
 
 void launch_grad_kinv_small(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,

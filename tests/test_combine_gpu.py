@@ -338,7 +338,9 @@ def test_default_mode_scenario_tasks_through_the_mirror(ctx):
     identical particles and are served from shared factorisations."""
     eng = autogp.HipEngine.__new__(autogp.HipEngine)
     eng.ctx = ctx
-    n = 200
+    # (long enough a series that a task's calls outlast a thread hand-over: at n = 200 a 6-item call
+    # is over in 0.15 ms since the short-series path, and the tasks no longer met)
+    n = 900
     vals = 100.0 + 0.3 * np.arange(n) + 3.0 * np.sin(np.arange(n) / 7.0) \
         + np.random.default_rng(6).standard_normal(n)
     base = mc.fitted(eng, values=vals, seed=43, n_particles=6, n_mcmc=1, n_hmc=1, smc_data_proportion=0.5)
