@@ -721,6 +721,7 @@ struct ngp_job {
     PinVec<unsigned char> h_in, h_out;
     size_t out_off[5] = {}, out_bytes = 0;
     bool zeroed = false, copy_in_flight = false;
+    bool out_fetched = false;   // h_out holds the result region of the last run
     // the spec the job was staged under: a later ngp_set_spec does not reach a staged job
     ngp_spec spec{};
     // lattice jobs: items whose reduced program is a chain of more than one instruction / the other
@@ -1454,10 +1455,20 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
         e.qpts = j->qpts;
     }
     tm.run(3, 0.0, 0.0, [&] { launch_epilogue(g, e, sp, s); });
+    // small results travel behind the last kernel, in the same queue: a fetch after the run's
+    // synchronisation would be a second host round trip (25 us of a 24-item call: the copy started
+    // that long after the epilogue had ended)
+    j->out_fetched = false;
+    if (j->out_bytes <= FETCH_PACKED_BYTES) {
+        j->h_out.resize(j->out_bytes);
+        if (hipMemcpyAsync(j->h_out.data(), j->info, j->out_bytes, hipMemcpyDeviceToHost, s) == hipSuccess)
+            j->out_fetched = true;
+    }
     hipError_t err = hipStreamSynchronize(s);
     if (err == hipSuccess) err = hipGetLastError();
     tm.resolve(c->prof);
     if (err != hipSuccess) return (ngp_status)err;
+    j->copy_in_flight = false;
     j->ran = true;
     return NGP_OK;
 }
@@ -1484,10 +1495,12 @@ extern "C" ngp_status ngp_job_fetch(ngp_job *j, double *logml_base, double *logm
     const JobGeom &g = j->g;
     hipStream_t s = c->stream;
     if (j->out_bytes <= FETCH_PACKED_BYTES) {   // small results: one copy of the whole region
-        j->h_out.resize(j->out_bytes);
-        HIPCHK(hipMemcpyAsync(j->h_out.data(), j->info, j->out_bytes, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        j->copy_in_flight = false;
+        if (!j->out_fetched) {                  // (normally ngp_job_run has brought it already)
+            j->h_out.resize(j->out_bytes);
+            HIPCHK(hipMemcpyAsync(j->h_out.data(), j->info, j->out_bytes, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            j->copy_in_flight = false;
+        }
         const unsigned char *h = j->h_out.data();
         if (info) std::memcpy(info, h + j->out_off[0], 4 * (size_t)g.B);
         if (logml_base) std::memcpy(logml_base, h + j->out_off[1], 8 * (size_t)g.B);
