@@ -197,7 +197,7 @@ struct SmallPlan {
     SmallSweep sw[SM_MAX_SWEEPS];
 };
 
-constexpr int SM_LDS_FIXED = 8 * (16 * 256 + 16 * 16 * SM_DSTR + 256 + 16 + 256 + 32);
+constexpr int SM_LDS_FIXED = 8 * (16 * 256 + 16 * 16 * SM_DSTR + 256 + 32);   // M_j | diagonal blocks | pivots | flags
 inline int small_lds_bytes(const SmallPlan &pl) { return SM_LDS_FIXED + pl.npanel * 2048; }
 
 // The plan of a geometry, or false when the column sweep has to do it (n0 > 256, structured

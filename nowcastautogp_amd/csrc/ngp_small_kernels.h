@@ -3,35 +3,40 @@
 // The column sweep of ngp_col_kernels.h is a chain of dependent launches per 64-wide block column
 // (chol_diag -> fat / thin / full step).  At the reference's everyday size — a few hundred points,
 // 24-64 particles (docs/vignettes/getting-started.jl:266-268) — that chain IS the call: 13-14
-// launches of 5-58 us, most of them a handful of workgroups.  Here one
-// 1,024-thread workgroup per item keeps the matrix in REGISTERS as 16 x 16 blocks in the
-// v_mfma_f64_16x16x4 C/D layout and sweeps it right-looking, 16 pivots per step:
+// launches of 5-58 us, most of them a handful of workgroups (DESIGN.md sections 4.9, 4.15).  Here one
+// 512-thread workgroup per item (8 waves, two per SIMD, 256 VGPRs each) keeps the matrix in
+// REGISTERS as 16 x 16 blocks in the v_mfma_f64_16x16x4 C/D layout and sweeps it right-looking,
+// 16 pivots per step:
 //
 //   wave 0 ("pivot wave")  owns nothing but the diagonal blocks' critical path: it applies the last
-//            rank-16 update to diagonal block j+1, factors it (one row per lane, pivots and
-//            multipliers broadcast by v_readlane — no barrier inside a block), inverts it and
-//            posts M = L_jj^-1 in MFMA operand order — all of it while the other waves run the
-//            trailing update of step j;
-//   waves 1..15 ("workers") own the blocks below the diagonal and the aux rows, round-robin over a
-//            column-major enumeration (the blocks still active at step j are a suffix of it, so
-//            every step is balanced to one block).  A block is held TRANSPOSED, T = (A_ik)': in the
-//            C/D layout lane (r, q), register s is T[4s+q][r] = A_ik[r][4s+q] — which is at once
-//            the B operand of the solve  X' = M C'  (no LDS round trip, ngp_kernels.hip header)
-//            and, written to LDS as it stands, the A and the B operand of every trailing update
-//            (A_ik)' -= L_kj L_ij' (contiguous, conflict-free ds_read_b64 for both).
+//            rank-16 update to diagonal block j+1, factors it (one row per lane, every broadcast a
+//            DPP row_newbcast, a reciprocal-only dependency chain — no barrier inside a block),
+//            inverts it and posts M = L_jj^-1 in MFMA operand order — all of it while the other
+//            waves run the trailing update of step j;
+//   waves 1..7 ("workers") own the blocks below the diagonal and the aux rows, twenty each,
+//            round-robin over a column-major enumeration (the blocks still active at step j are a
+//            suffix of it, so every step is balanced to one block).  A block is held TRANSPOSED,
+//            T = (A_ik)': in the C/D layout lane (r, q), register s is T[4s+q][r] = A_ik[r][4s+q] —
+//            which is at once the B operand of the solve  X' = M C'  (no LDS round trip,
+//            ngp_kernels.hip header) and, written to LDS as it stands, the A and the B operand of
+//            every trailing update (A_ik)' -= L_kj L_ij' (contiguous, conflict-free ds_read_b64).
 //   The diagonal blocks live in LDS (row stride 17); the ones not next in line are updated by the
 //   workers, one block each per step.
 //
-// Two barriers per step; the step's critical path is the pivot wave's 16 x 16 factorisation +
-// inverse (~2 us), not a launch.  Aux rows that do not fit the register file beside the main block
-// (gradient jobs: the identity rows that become W_I = L^-T) are swept afterwards in the same launch
-// against the finished factor (its panels come back from L2 one step ahead, the M_j are still in
-// LDS), on all 16 waves.
+// Two LDS-only barriers per step; the step's critical path is the pivot wave's 16 x 16 block
+// (1.3-2.3 us), not a launch.  Aux rows that do not fit the register file beside the main block are
+// swept afterwards in the same launch against the finished factor (its panels come back from L2
+// one step ahead, the M_j are still in LDS), on all 8 waves; a gradient job's identity rows —
+// W_I = L^-T — are not swept at all: every block column of L^-1 is one wave's task, barrier-free
+// (small_inverse_column).  grad_kinv_small_kernel (K^-1 and alpha of such a job, one wave per
+// 16 x 16 block) and chol_diag_wave_kernel (the same pivot wave on the 64 x 64 diagonal blocks of
+// the column sweep, for small chunks) live here too.
 //
-// The slab layout (ngp_kernels.hip header), logdet, info and the aux rows W = X L^-T are exactly
-// what the column sweep leaves, so everything downstream (gram / epilogue, K^-1, the contraction)
-// is unchanged.  Results differ from the column sweep in the last bits (other summation order);
-// an item's bits do not depend on the batch it travels in.
+// What the launch leaves in the slab is what its consumers read — the aux rows W = X L^-T of a value
+// job, of a gradient job the blocks of W_I on and right of the block diagonal and z' — plus logdet
+// and info; L itself only when a later sweep of the launch reads it back.  Results differ from the
+// column sweep in the last bits (other summation order); an item's bits do not depend on the batch
+// it travels in.
 #pragma once
 #include <atomic>
 #include <type_traits>
@@ -43,10 +48,7 @@ namespace ngp {
 struct SmallLds {
     double *Minv;     // [16][4][64]   M_j = L_jj^-1 in operand order: [t][m + 16 c] = M[m][4t + c]
     double *Dg;       // [16][16 x 17] diagonal blocks (full symmetric) until they are factored
-    double *Lrow;     // [16][16]      L_jj of the block being inverted
-    double *rdg;      // [16]          reciprocals of its diagonal
     double *diagL;    // [256]         the pivots d = diag(L)^2, for logdet
-    int    *colstart; // [17]          first enumeration index of every block column of the sweep
     int    *bad;      // first failed pivot + 1
     double *Panel;    // [npanel][4][64] the finished blocks of column j, operand order
 };
@@ -243,8 +245,8 @@ __device__ __forceinline__ void small_sweep(const JobGeom &g, const ChunkPtrs &p
     int bk[SM_NSLOT], bw[SM_NSLOT];
     f64x4 acc[SM_NSLOT];
     // (a wave's slots ascend through the column-major enumeration: the scan for a slot's column
-    // carries on where the previous slot's ended — in registers; a lookup of colstart[] in LDS per
-    // probe made this prologue 10 us)
+    // carries on where the previous slot's ended — in registers; a table of column starts in LDS,
+    // one lookup per probe, made this prologue 10 us)
     int sk = 0, scs = 0, scnt = small_col_count(sw, nbe, 0);
 #pragma unroll
     for (int s = 0; s < SM_NSLOT; ++s) {
@@ -499,11 +501,8 @@ __global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, Chunk
     SmallLds L;
     L.Minv = sm_lds;
     L.Dg = L.Minv + 16 * 256;
-    L.Lrow = L.Dg + 16 * 16 * SM_DSTR;
-    L.rdg = L.Lrow + 256;
-    L.diagL = L.rdg + 16;
-    L.colstart = reinterpret_cast<int *>(L.diagL + 256);
-    L.bad = L.colstart + 32;
+    L.diagL = L.Dg + 16 * 16 * SM_DSTR;
+    L.bad = reinterpret_cast<int *>(L.diagL + 256);
     L.Panel = L.diagL + 256 + 32;
     const int item = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -672,10 +671,7 @@ __global__ __launch_bounds__(256, 4) void chol_diag_wave_kernel(JobGeom g, Chunk
     SmallLds L;
     L.Minv = Minv;
     L.Dg = Dg;
-    L.Lrow = nullptr;
-    L.rdg = nullptr;
     L.diagL = dL;
-    L.colstart = misc;
     L.bad = misc + 1;
     L.Panel = Pan;
     NoProbe probe;

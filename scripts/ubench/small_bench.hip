@@ -120,7 +120,8 @@ int main(int argc, char **argv) {
         for (int r = 0; r < n0; ++r) {
             if (r < nr) ld_ref += log(Sx[(size_t)r * n0 + r]);
             for (int c = 0; c < n0; ++c)
-                if (c / 16 <= r / 16 && r < 16 * pl.nbe)     // the 16-blocks on and below the diagonal, data rows
+                if (c / 16 < r / 16 && r < 16 * pl.nbe)      // the 16-blocks below the diagonal, data rows (the
+                                                              // diagonal blocks' factors stay in the pivot wave)
                     eL = std::max(eL, fabs(out[(size_t)r * n0 + c] - (c <= r ? Sx[(size_t)r * n0 + c] : 0.0)));
         }
         // W = X S^-T by forward substitution on the host
