@@ -2205,7 +2205,9 @@ struct LeafRun {
                                launch_aux_back(g, p, p.dinv, mstep, (double *)d_kinv, 0, bc, cc, s);
                            });
             } else {
-                const bool short_job = small_job(g, bc);   // factor_chunk's rule
+                // short jobs (factor_chunk's rule), and small chunks of series up to 448 points on the
+                // column sweep: its W_I has the same entries where the 16 x 16-block kernel reads them
+                const bool short_job = small_job(g, bc) || (g.nb0 < 8 && bc <= AHEAD_EARLY_MAX_ITEMS && !g.invariant);
                 tm.run(5, bc * n3 / 3.0, bc * 8.0 * 1.5 * (double)g.n0 * g.n0, [&] {
                     if (short_job)
                         launch_grad_kinv_small(g, (const double *)d_L, (double *)d_kinv, (double *)d_alpha,
