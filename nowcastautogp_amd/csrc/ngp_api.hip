@@ -1403,11 +1403,15 @@ extern "C" ngp_status ngp_job_run(ngp_job *j) {
                 (g.toep ? (double)p.n_fill_single * ((double)g.n0 * (g.n0 - NB) / 2.0) : 0.0);
             tm.run(4, 0.0, 8.0 * fill_elems, [&] { launch_fill(g, p, bc, sp, s); });
             if (mixed) HIPCHK(hipMemsetAsync(order_prev, 0, 4 * (size_t)bc, s));
+            double *Gchunk = j->G + (int64_t)b0 * g.naux * g.naux;
+            // short jobs: the one launch of the factorisation leaves G too
+            const bool gram_inside = !mixed && mstep == 0 && small_job(g, bc);
+            if (gram_inside) p.G = Gchunk;
             factor_chunk(ln, g, p, bc, tm, mstep, mixed ? &sp : nullptr, (int32_t *)order_buf,
                          (unsigned *)order_prev);
-            double *Gchunk = j->G + (int64_t)b0 * g.naux * g.naux;
-            tm.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0,
-                   [&] { launch_gram(g, (const double *)Lbuf, Gchunk, bc, s); });
+            if (!gram_inside)
+                tm.run(2, bc * nrows_aux * nrows_aux * g.n0, bc * 8.0 * nrows_aux * g.n0,
+                       [&] { launch_gram(g, (const double *)Lbuf, Gchunk, bc, s); });
             if (mixed) {
                 std::vector<unsigned> hc(2 * (size_t)bc);
                 HIPCHK(hipMemcpyAsync(hc.data(), cnt, 8 * (size_t)bc, hipMemcpyDeviceToHost, s));

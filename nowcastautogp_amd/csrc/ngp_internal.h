@@ -145,6 +145,8 @@ struct ChunkPtrs {
     // through the general fill
     const int32_t *fill_chain, *fill_other, *fill_single;
     int32_t n_fill_chain, n_fill_other, n_fill_single, fill_base;
+    double       *G;      // short value jobs: [Bc][naux x naux] — chol_small_kernel leaves the Gram matrix
+                          // of the aux rows itself (gram_kernel's arithmetic, one launch less); else null
     const int32_t *items; // refinement sweeps: the items (indices into the chunk) a launch works
                           // on, Bc = their count; null: all of them in order
     // small chunks only (null otherwise): split-k fat steps, see chol_col_glds_kernel<.., SPLITK>

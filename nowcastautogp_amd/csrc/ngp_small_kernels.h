@@ -545,6 +545,27 @@ __global__ __launch_bounds__(SM_THREADS) void chol_small_kernel(JobGeom g, Chunk
     }
     if (wave == 0 && lane == 0 && badl) *L.bad = badl;
     __syncthreads();
+    // G = W W' of the aux rows, here instead of in a launch of its own (gram_kernel: 20 us of a
+    // 24-item call's 130; this tail: 11): one pair of rows per thread, the serial dot product of
+    // gram_kernel's short-row form — the same operations in the same order, so the same bits for the
+    // same W.  (Four threads per pair, a quarter of the columns each, was slower: 15 us.)
+    if (p.G) {
+        const double *W = S + (long)g.n0 * ld;
+        double *Go = p.G + (long)item * g.naux * g.naux;
+        for (int e = tid; e < g.naux * g.naux; e += SM_THREADS) {
+            const int a = e / g.naux, b = e % g.naux;
+            if (b > a) continue;
+            const double *wa = W + (long)a * ld, *wb = W + (long)b * ld;
+            double s0 = 0.0, s1 = 0.0;
+            for (int k = 0; k < g.n0; k += 2) {
+                s0 += wa[k] * wb[k];
+                s1 += wa[k + 1] * wb[k + 1];
+            }
+            const double sv = s0 + s1;
+            Go[a * g.naux + b] = sv;
+            Go[b * g.naux + a] = sv;
+        }
+    }
     // logdet = sum of log diag(L) over the data rows (padding rows are identity)
     if (wave == 0) {
         double s = 0.0;
