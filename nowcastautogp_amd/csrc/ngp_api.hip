@@ -1055,7 +1055,8 @@ ngp_status stage_general(ngp_ctx *c, int P, const ngp_kernel *kernels, int n, co
     g.invariant = c->invariant ? 1 : 0;
     g.short_series = c->short_series ? 1 : 0;
     // (short series are factorised from registers in one launch and store every tile)
-    if (c->toeplitz && c->spec.precision != NGP_PREC_MIXED && !(g.short_series && g.nb0 <= 4))
+    if (c->toeplitz && c->spec.precision != NGP_PREC_MIXED &&
+        !(g.short_series && g.nb0 <= 4 && (P <= SM_MAX_ITEMS || g.invariant)))
         g.toep = toep_stride;
     ngp_job *j = new (std::nothrow) ngp_job();
     if (!j) return NGP_ERR_TOO_LARGE;
@@ -2439,7 +2440,10 @@ static ngp_status grad_stage_impl(ngp_ctx *c, int32_t B, const ngp_kernel *kerne
     }
     // (series of up to 256 points: the general leaf factorises them in one launch,
     // ngp_small_kernels.h — shorter than the Toeplitz leaf's chain of sweeps)
-    if (on && n >= 2 * NB && n <= 8192 && !(short_series && n <= 4 * NB)) {
+    // (batches beyond what the one-launch path takes, SM_MAX_ITEMS, keep the Toeplitz leaf: there it is
+    // the faster one — 8,192 stationary items at n = 208: 14.8 against 21.3 ms; batch-invariant contexts
+    // route by the series alone)
+    if (on && n >= 2 * NB && n <= 8192 && !(short_series && n <= 4 * NB && (B <= SM_MAX_ITEMS || invariant))) {
         std::vector<double> real(t, t + n);
         std::vector<int32_t> q;
         double hh = 0.0;

@@ -179,7 +179,7 @@ constexpr int SM_NSLOT = 20;           // register blocks per wave (8 VGPRs each
 constexpr int SM_DSTR = 17;            // row stride of a diagonal block in LDS (doubles)
 constexpr int SM_MAX_PANEL = 34;       // panel blocks of one step: main rows + the sweep's aux row-blocks
 constexpr int SM_MAX_SWEEPS = 4;
-constexpr int SM_MAX_ITEMS = 2048;     // larger chunks fill the chip on the column sweep
+constexpr int SM_MAX_ITEMS = 4096;      // larger chunks fill the chip on the column sweep (measured: 24 x n = 208 scenarios x particles up to 4,096 items win here, 8,192 gradient items lose)
 
 // One sweep over the block columns.  Aux row-blocks taken along: identity rows [i0, i1) (gradient
 // jobs: row-block a is e_(16a..16a+15)', it joins at column a and stays upper triangular) and dense
