@@ -920,13 +920,17 @@ void launch_grad_kinv_small(const JobGeom &g, const double *L, double *Kinv, dou
 
 void launch_chol_small(const JobGeom &g, const ChunkPtrs &p, int Bc, const SmallPlan &pl,
                        hipStream_t s) {
-    // more LDS than the 64 KiB a kernel gets unasked: once per process (the attribute is the kernel's)
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set.load(std::memory_order_acquire)) {
+    // more LDS than the 64 KiB a kernel gets unasked: once per device of the process (the attribute
+    // belongs to the kernel's image on that device)
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_acquire) & bit)) {
         (void)hipFuncSetAttribute((const void *)chol_small_kernel<NoProbe>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                   SM_LDS_FIXED + SM_MAX_PANEL * 2048);
-        attr_set.store(true, std::memory_order_release);
+        attr_set.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(chol_small_kernel<NoProbe>, dim3(Bc), dim3(SM_THREADS), small_lds_bytes(pl), s, g, p, pl);
 }

@@ -37,6 +37,7 @@ static bool inside(const void *p, size_t n) {
 }
 
 hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+hipError_t hipGetDevice(int *d) { *d = 0; return 0; }
 hipError_t hipFuncSetAttribute(const void *, int, int) { return 0; }
 hipError_t hipSetDevice(int) { return 0; }
 hipError_t hipMemGetInfo(size_t *fr, size_t *tot) { *fr = *tot = (size_t)2 << 30; return 0; }
