@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void grad_kinv_small_kernel(JobGeom g, const d
 // layout is then already the transposed block the sweep works on (ngp_small_kernels.h header), so
 // every block stays in the wave that staged it.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 4) void chol_diag_wave_kernel(JobGeom g, ChunkPtrs p, int j, int k0) {
+__global__ __launch_bounds__(256, 2) void chol_diag_wave_kernel(JobGeom g, ChunkPtrs p, int j, int k0) {
     __shared__ double Dg[4 * 16 * SM_DSTR];   // the four diagonal 16 x 16 blocks (full symmetric)
     __shared__ double Minv[4 * 256];          // M_i = L_ii^-1, operand order
     __shared__ double Pan[4 * 256];           // the solved blocks of the current block column, by row block
