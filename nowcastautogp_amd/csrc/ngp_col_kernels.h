@@ -1037,8 +1037,9 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc4[a][b][r] = 0.0;
 
-    // one 16-deep fp64 chunk in buffer `buf`: 256 mfma4 per wave.  (Requesting the operands of
-    // k-step s+1 before the MFMAs of k-step s — two register sets — measured 1 % slower.)
+    // one 16-deep fp64 chunk in buffer `buf`: 256 mfma4 per wave, for a tile that works on fewer
+    // than its four 16-row groups; full tiles take mult_chunk_pipelined (ngp_mfma.h).  (Requesting ALL
+    // operands of k-step s+1 before the MFMAs of k-step s — two register sets — measured 1 % slower.)
     auto mult64 = [&](const char *buf, auto nit_c) {
         constexpr int NIT = decltype(nit_c)::value;
 #pragma unroll
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
                 for (int c = 0; c < nchunks; ++c) {
                     const int cur = c & 1;
                     if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
-                    mult64(smem + cur * STAGE, std::integral_constant<int, 4>{});
+                    mult_chunk_pipelined<2 * BLKB>(acc4, smem + cur * STAGE, a_addr, b_addr);
                     __syncthreads();
                     if (c == 0) probe.mark(1);
                     if (c == nchunks / 2) probe.mark(2);
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
                     stage(cur ^ 1, kt_cur * NB + LDS_KC * sub);
                     ++sub;
                 }
-                mult64(smem + cur * STAGE, std::integral_constant<int, 4>{});
+                mult_chunk_pipelined<2 * BLKB>(acc4, smem + cur * STAGE, a_addr, b_addr);
                 __syncthreads();
             }
         }

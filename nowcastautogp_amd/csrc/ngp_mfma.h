@@ -63,6 +63,65 @@ __device__ __forceinline__ void mfma16_as_4(double (&acc)[4], double a, const Ro
     acc[2] = mfma4(a, b.r2, acc[2]);
     acc[3] = mfma4(a, b.r3, acc[3]);
 }
+// One 16-deep chunk of the fat step's LDS image (ngp_col_kernels.h: chol_col_glds_kernel) into the
+// wave's 64 x 64 tile — 256 4x4x4 MFMAs —, the LDS reads software-pipelined: the operands of row
+// group 0 of k-step s + 1 (and its A values) are requested under the last sixteen MFMAs of k-step
+// s, the operands of row groups 1..3 under the first sixteen of their own step.  A wave that has
+// its SIMD to itself (its partner in an epilogue) no longer waits out an LDS round trip per
+// k-step (+8 VGPRs).  a_addr[s] / b_addr[r][s]: the swizzled read addresses of k-step s (rotation
+// r); GRP: bytes between the 16-row groups of a fragment.  Per accumulator the k-steps arrive in
+// ascending order, as in the plain loop: bit-identical to it.  (Carried across the chunk's
+// barrier too — the barrier before the last sixteen MFMAs, the next chunk's first operands
+// requested behind it — it was slower: profiles/r04/lds_read_pipeline.txt.)
+template <int GRP>
+__device__ __forceinline__ void mult_chunk_pipelined(double (&acc4)[4][4][4], const char *buf,
+                                                     const unsigned (&a_addr)[4],
+                                                     const unsigned (&b_addr)[4][4]) {
+    auto ld_a = [&](int s, double (&a)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            a[u] = *reinterpret_cast<const double *>(buf + a_addr[s] + u * GRP);
+    };
+    auto ld_b = [&](int s, int it, Rot4 &br) {
+        br.r0 = *reinterpret_cast<const double *>(buf + b_addr[0][s] + it * GRP);
+        br.r1 = *reinterpret_cast<const double *>(buf + b_addr[1][s] + it * GRP);
+        br.r2 = *reinterpret_cast<const double *>(buf + b_addr[2][s] + it * GRP);
+        br.r3 = *reinterpret_cast<const double *>(buf + b_addr[3][s] + it * GRP);
+    };
+    double a[4];
+    Rot4 b0;
+    ld_a(0, a);
+    ld_b(0, 0, b0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        Rot4 b1, b2, b3;
+        ld_b(s, 1, b1);
+        ld_b(s, 2, b2);
+        ld_b(s, 3, b3);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][0], a[jt], b0);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][1], a[jt], b1);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][2], a[jt], b2);
+        __builtin_amdgcn_sched_barrier(0);
+        double an[4];
+        Rot4 b0n;
+        if (s < 3) {
+            ld_a(s + 1, an);
+            ld_b(s + 1, 0, b0n);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) mfma16_as_4(acc4[jt][3], a[jt], b3);
+        if (s < 3) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = an[u];
+            b0 = b0n;
+        }
+    }
+}
 // four block-diagonal accumulators -> the 16x16x4 C/D layout (reg s, lane (n, q): D[q + 4s][n])
 __device__ __forceinline__ f64x4 to_d16(const double (&c)[4]) {
     f64x4 o;
