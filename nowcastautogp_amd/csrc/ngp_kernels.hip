@@ -1610,16 +1610,28 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const 
         __syncthreads();
     }
     if (!valid) return;
-    double *Ko = Kinv + (long)item * g.n0 * g.n0;
+    // The tile leaves as full 512-byte rows: sixteen rows at a time through a per-wave LDS tile (the
+    // stage buffers are free: every wave passed the loop's last barrier), 32 store instructions of
+    // 1 KiB instead of 64 that scatter 32-byte pieces over sixteen rows each
+    // (profiles/r04/kinv_experiments.txt: the stores were 30 of the kernel's 710 ms).
+    double *Ko = Kinv + (long)item * g.n0 * g.n0 + (long)(I * NB) * g.n0 + J * NB;
+    constexpr int PITCH = NB + 2;   // doubles: rows stay 16-byte aligned, row groups on distinct banks
+    double *tl = reinterpret_cast<double *>(smem) + wave * (16 * PITCH);
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int it = 0; it < 4; ++it) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int jt = 0; jt < 4; ++jt) {
             const f64x4 d = to_d16(acc4[jt][it]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                Ko[(long)(I * NB + 16 * it + r16) * g.n0 + J * NB + 16 * jt + q + 4 * s] = d[s];
+            for (int s = 0; s < 4; ++s) tl[r16 * PITCH + 16 * jt + q + 4 * s] = d[s];
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 2 * i + (lane >> 5), c2 = 2 * (lane & 31);
+            const f64x2 v = *reinterpret_cast<const f64x2 *>(tl + row * PITCH + c2);
+            *reinterpret_cast<f64x2 *>(Ko + (long)(16 * it + row) * g.n0 + c2) = v;
+        }
+    }
 }
 
 // alpha[a] = sum_k W[a][k] z[k] (z = the data row of W), quad = z'z; one wave per row
