@@ -600,6 +600,59 @@ __device__ __forceinline__ void subtract_in_place_perm(double *rows, long ld, in
     }
 }
 
+// The same update with the tile travelling as full 512-byte rows: the lane's sixteen values of a
+// 16-row group go through the wave's LDS tile `tl` (16 rows x EPI_PITCH doubles: the layout the solve
+// writes its rows from), every load and store instruction then covers two whole rows, where the
+// register form above touches sixteen rows with 32 bytes each (64 + 64 such instructions per tile; the
+// same change took 19 of 714 ms off the K^-1 kernel, profiles/r04/kinv_experiments.txt).  Operands
+// and operation per element are the register form's: bit-identical.
+__device__ __forceinline__ void subtract_in_place_rows(double *rows, long ld, int c0,
+                                                       const double (*acc4)[4][4], int lane,
+                                                       double *tl, bool fresh = false,
+                                                       const double *ksl = nullptr, int nit = 4) {
+    const int n16 = lane & 15, isub = lane >> 4;
+    const int jj0 = 4 * (n16 >> 2) + isub;
+    const int hrow = lane >> 5, c2 = 2 * (lane & 31);
+    double *base = rows + c0 + c2;
+    auto load_rows = [&](int it, f64x2 (&kv)[8]) {
+        if (ksl) {   // tile[i][jj] = ksl[63 + i - jj]
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int d = 63 + 16 * it + 2 * i + hrow - c2;
+                kv[i].x = ksl[d];
+                kv[i].y = ksl[d - 1];
+            }
+        } else if (fresh) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) kv[i].x = kv[i].y = 0.0;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                kv[i] = *reinterpret_cast<const f64x2 *>(base + (long)(16 * it + 2 * i + hrow) * ld);
+        }
+    };
+    f64x2 kv[2][8];
+    load_rows(0, kv[0]);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (it >= nit) break;       // an aux tile's zero rows stay as they are
+        if (it + 1 < nit) load_rows(it + 1, kv[(it + 1) & 1]);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tl[((n16 + 4 * r) & 15) * EPI_PITCH + 16 * jt + jj0] = acc4[jt][it][r];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f64x2 a = *reinterpret_cast<const f64x2 *>(tl + (2 * i + hrow) * EPI_PITCH + c2);
+            f64x2 o;
+            o.x = kv[it & 1][i].x - a.x;
+            o.y = kv[it & 1][i].y - a.y;
+            *reinterpret_cast<f64x2 *>(base + (long)(16 * it + 2 * i + hrow) * ld) = o;
+        }
+    }
+}
+
 // JobGeom::toep: the 127 table entries a structured item's tile (rows row0.., columns col0.. of the
 // main block, row0 >= col0 + 64) is regenerated from, into the wave's LDS slice:
 // ksl[x] = tab[toep (row0 - col0 - 63 + x)]
@@ -1349,7 +1402,9 @@ __global__ __launch_bounds__(256, 2) void chol_col_glds_kernel(JobGeom g, ChunkP
 
     double *Lr = Lit + tile_row0(tile) * ld;
     if (col) {
-        subtract_in_place_perm(Lr, ld, (j + 1) * NB, acc4, lane, IDENT && synth != 0, ksl, nit);
+        subtract_in_place_rows(Lr, ld, (j + 1) * NB, acc4, lane,
+                               reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES),
+                               IDENT && synth != 0, ksl, nit);
     } else if constexpr (MIXED) {
         const int rt = (tile < st.nmain) ? j + 1 + tile : g.nb0 + (tile - st.nmain);
         solve_and_store_lds<true>(
