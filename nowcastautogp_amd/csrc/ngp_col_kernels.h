@@ -426,7 +426,7 @@ __device__ __forceinline__ void stage_mstrips(double *lds_m, const double *mstri
 // ksl (JobGeom::toep, structured items, a tile no step has touched yet): the tile was never
 // written — K[i][jj] = ksl[63 + i - jj], the 127 table entries of the tile's lattice distances,
 // staged in LDS by the caller (struct_slice); null: read the stored tile.
-template <bool SHADOW = false, bool SYNTH = false, class Probe = NoProbe>
+template <bool SHADOW = false, bool SYNTH = false, class Probe = NoProbe, bool KROWS = false>
 __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], double *Lr,
                                                     const double *lds_m, long ld, int kmax,
                                                     int lane, double *buf, Probe &probe,
@@ -439,11 +439,22 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
     // 63 + i - jj = [15 + ((n16 + 4r) & 15) - jj0] + 16 (it - jt + 3): a per-lane base and a
     // compile-time offset
     const double *ksl0 = ksl ? ksl + 15 - jj0 : nullptr;
-    double kv[4][4];
+    f64x2 kvr[8];
+    double kvp[4][4];
+    const int hrow = lane >> 5, c2 = 2 * (lane & 31);
+    // KROWS (the thin steps): a stored tile arrives as full 512-byte rows — eight loads of two rows
+    // each, requested one pass ahead, where the register layout asks for sixteen loads of sixteen
+    // 32-byte pieces — and is turned into the register layout through the wave's LDS tile at the
+    // head of its pass (the tile is free then: the previous pass's rows have been read out of
+    // it).  Thin steps 95.5 -> 91.7 ms (C3), 188.7 -> 179.8 (fitted gradient); in the fat steps
+    // the LDS round trip costs what the row loads gain (+2 ms): they keep the register loads.
+    // from_rows: wave-uniform, the tile is a stored one (not a table slice, not synthesised)
+    bool from_rows = KROWS && ksl0 == nullptr;
+    if constexpr (SYNTH) from_rows = from_rows && synth == 0;
     // the source is tested once per 16-row group, outside the element loops: tested per element it
     // puts every load into a basic block of its own and the sixteen loads of a group are no longer
     // issued together
-    auto load_k = [&](int it) {
+    auto k_elems = [&](int it, double (&kv)[4][4]) {
         if (ksl0) {
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
@@ -464,23 +475,57 @@ __device__ __forceinline__ void solve_and_store_lds(const double (*acc4)[4][4], 
                 return;
             }
         }
+        if constexpr (!KROWS) {
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * it + ((n16 + 4 * r) & 15);
-                kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * it + ((n16 + 4 * r) & 15);
+                    kv[jt][r] = Lr[(long)i * ld + kmax + 16 * jt + jj0];
+                }
+        }
+    };
+    auto load_k = [&](int it) {   // one pass ahead
+        if constexpr (KROWS) {
+            if (!from_rows) return;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                kvr[i] = *reinterpret_cast<const f64x2 *>(Lr + (long)(16 * it + 2 * i + hrow) * ld + kmax + c2);
+        } else {
+            k_elems(it, kvp);
+        }
+    };
+    auto take_k = [&](int it, double (&kv)[4][4]) {   // at the head of pass `it`
+        if constexpr (KROWS) {
+            if (!from_rows) {
+                k_elems(it, kv);
+                return;
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f64x2 *>(buf + (2 * i + hrow) * EPI_PITCH + c2) = kvr[i];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    kv[jt][r] = buf[((n16 + 4 * r) & 15) * EPI_PITCH + 16 * jt + jj0];
+        } else {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kv[jt][r] = kvp[jt][r];
+        }
     };
     load_k(0);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {                // 16 tile rows per pass
         if (it >= nit) break;                       // an aux tile's zero rows: nothing to solve or store
         double c4[4][4];   // C' = K' - S' for this 16-row group of the tile
+        take_k(it, c4);
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) c4[jt][r] = kv[jt][r] - acc4[jt][it][r];
+            for (int r = 0; r < 4; ++r) c4[jt][r] = c4[jt][r] - acc4[jt][it][r];
         probe.mark_after(12 + 3 * it, c4[3][3] + c4[0][0] + c4[1][2] + c4[2][1]);
         if (it + 1 < nit) load_k(it + 1);
         // 16 strip groups cb4 = 4 ct + cq (output rows 4 cb4 ..: C' tiles jt <= ct).  The M strips of
@@ -889,7 +934,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
     double *buf = reinterpret_cast<double *>(smem + EPI_M_BYTES + wave * EPI_WAVE_BYTES);
     if constexpr (MIXED) {
         const int rt = (tile < st.nmain) ? j + 1 + tile : g.nb0 + (tile - st.nmain);
-        solve_and_store_lds<true>(
+        solve_and_store_lds<true, false, Probe, true>(
             acc4, Lr, reinterpret_cast<const double *>(smem), ld, kmax, lane, buf, probe,
             p.L32 + (long)item * g.item_stride + rowbase * ld,
             p.tmax + (long)item * (g.nb0 + g.naux_pad / NB) * g.nb0 + tmax_index(g, rt, j));
@@ -897,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void chol_col_thin_kernel(JobGeom g, ChunkP
         // an aux tile with at most 16 real rows: its other rows are zero and stay zero (fat kernel)
         int nit = (tile >= st.nmain && g.naux - NB * (tile - st.nmain) <= 16) ? 1 : 4;
         if (IDENT && tile < st.nmain && g.n_real - NB * (j + 1 + tile) <= 16) nit = 1;   // padded last row tile
-        solve_and_store_lds<false, IDENT>(acc4, Lr, reinterpret_cast<const double *>(smem), ld,
+        solve_and_store_lds<false, IDENT, Probe, true>(acc4, Lr, reinterpret_cast<const double *>(smem), ld,
                                           kmax, lane, buf, probe, nullptr, nullptr, synth, nullptr,
                                           nit);
     }
