@@ -1503,7 +1503,8 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_kernel(JobGeom g, const doub
 // go to one XCD: the 136 blocks of an item at n = 2048 read its 18 MB of W thirteen times over
 // (PMC: 200 MB of fetches per item, 3.2 TB/s) and only an L2 they share can absorb that.
 __global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const double *L,
-                                                               double *Kinv, int nblk, int Bc) {
+                                                               double *Kinv, int nblk, int Bc,
+                                                               double *alpha) {
     constexpr int ROWB = 128, BLKB = 8 * ROWB + 128, STAGE = 32 * BLKB;
     auto row_off = [](int row) { return (row >> 3) * BLKB + (row & 7) * ROWB; };
     __shared__ __attribute__((aligned(1024))) char smem[2 * STAGE];
@@ -1582,12 +1583,35 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const 
     // the first 64 columns of the k-range for the waves of row tile I0 + 1, whose rows are the
     // stored zeros of block (I0 + 1, I0) there.  Adding those zero products changed no bit.
     const int skip_chunks = __builtin_amdgcn_readfirstlane(!valid ? nchunks : (ltile == 1 ? NB / LDS_KC : 0));
+    // alpha = W_I z for the rows of this block row's two row tiles, from the rows the workgroup
+    // stages anyway (block pairs with bj = 0: one per block row; W[a][k] = 0 left of a's block
+    // column, so the k-range of the block pair is the whole sum): thread (row, half) takes eight
+    // of a chunk's sixteen columns.  The separate kernel read every row of W once more from HBM
+    // (18.5 MB per item) beside this one and cost it 22 of its 713 ms.
+    const bool do_alpha = alpha != nullptr && bj == 0;   // workgroup-uniform
+    const int arow = tid >> 1, ahalf = tid & 1;          // LDS row 128 + arow: row arow of (I0, I0 + 1)
+    const double *zrow = Wb + (long)g.n0 * ld;           // the data row of W
+    const unsigned a_off = (unsigned)row_off(128 + arow);
+    const int a_key = (arow >> 1) & 7;
+    double asum = 0.0;
     stage(0, kbeg);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
         if (c + 1 < nchunks) stage(cur ^ 1, kbeg + (c + 1) * LDS_KC);
         const char *buf = smem + cur * STAGE;
+        // (the rows of tile I0 + 1 start at their own block column: what lies left of it is never
+        // written — wave-uniform: waves 2, 3 hold those rows)
+        if (do_alpha && (arow < NB || c >= NB / LDS_KC)) {
+            const double *zc = zrow + kbeg + c * LDS_KC + 8 * ahalf;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const f64x2 w = *reinterpret_cast<const f64x2 *>(buf + a_off + (((4 * ahalf + pp) ^ a_key) << 4));
+                const f64x2 zz = *reinterpret_cast<const f64x2 *>(zc + 2 * pp);
+                asum = fma(w.x, zz.x, asum);
+                asum = fma(w.y, zz.y, asum);
+            }
+        }
         if (c >= skip_chunks) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -1608,6 +1632,11 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const 
             }
         }
         __syncthreads();
+    }
+    if (do_alpha) {
+        asum += __shfl_xor(asum, 1, 64);
+        const int trow = (I0 + (arow >> 6)) * NB + (arow & 63);
+        if (ahalf == 0 && I0 + (arow >> 6) < g.nb0) alpha[(long)item * g.n0 + trow] = asum;
     }
     if (!valid) return;
     // The tile leaves as full 512-byte rows: sixteen rows at a time through a per-wave LDS tile (the
@@ -1636,10 +1665,10 @@ __global__ __launch_bounds__(256, 2) void grad_kinv_lds_kernel(JobGeom g, const 
 
 // alpha[a] = sum_k W[a][k] z[k] (z = the data row of W), quad = z'z; one wave per row
 __global__ __launch_bounds__(256) void grad_alpha_kernel(JobGeom g, const double *L, double *alpha,
-                                                         double *quad) {
+                                                         double *quad, int a_first) {
     const int item = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int a = blockIdx.x * 4 + wave;   // a == n0: the quadratic form
+    const int a = a_first + blockIdx.x * 4 + wave;   // a == n0: the quadratic form
     if (a > g.n0) return;
     const double *W = L + (long)item * g.item_stride + (long)g.n0 * g.ld;
     const double *wa = W + (long)a * g.ld, *z = W + (long)g.n0 * g.ld;
@@ -2857,21 +2886,25 @@ void launch_diag_ahead(const JobGeom &g, const ChunkPtrs &p, int Bc, int j, hipS
 
 void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *alpha, double *quad,
                       int Bc, hipStream_t s, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
-    // alpha = W_I z reads every row of W once (18.5 MB per item at n = 2048: HBM-bound) and does not
-    // depend on K^-1 (MFMA-bound): it runs beside it on the side stream
+    // long series (2 x 2 tile blocks staged through LDS): alpha = W_I z comes out of the K^-1 kernel
+    // itself, from the rows it stages; the alpha kernel is left with the quadratic form z'z (one
+    // wave per item).  Shorter series: alpha reads every row of W once and does not depend on K^-1:
+    // it runs beside it on the side stream.
+    const bool lds = g.nb0 >= 8;
+    const int a_first = lds ? g.n0 : 0;
+    const dim3 agrid(lds ? 1 : (g.n0 + 1 + 3) / 4, Bc);
     const bool beside = side && fork && join;
     if (beside) {
         (void)hipEventRecord(fork, s);
         (void)hipStreamWaitEvent(side, fork, 0);
-        hipLaunchKernelGGL(grad_alpha_kernel, dim3((g.n0 + 1 + 3) / 4, Bc), dim3(256), 0, side, g, L,
-                           alpha, quad);
+        hipLaunchKernelGGL(grad_alpha_kernel, agrid, dim3(256), 0, side, g, L, alpha, quad, a_first);
         (void)hipEventRecord(join, side);
     }
     const int npairs = g.nb0 * (g.nb0 + 1) / 2;
-    if (g.nb0 >= 8) {   // long series: 2 x 2 tile blocks staged through LDS (HBM traffic halves)
+    if (lds) {   // HBM traffic halves against the wave-per-tile form
         const int nb2 = (g.nb0 + 1) / 2, nblk = nb2 * (nb2 + 1) / 2;
         hipLaunchKernelGGL(grad_kinv_lds_kernel, dim3(nblk * ((Bc + 7) / 8 * 8)), dim3(256), 0, s, g, L,
-                           Kinv, nblk, Bc);
+                           Kinv, nblk, Bc, alpha);
     } else {
         hipLaunchKernelGGL(grad_kinv_kernel, dim3((npairs + 3) / 4, Bc), dim3(256), 0, s, g, L, Kinv,
                            npairs);
@@ -2879,8 +2912,7 @@ void launch_grad_kinv(const JobGeom &g, const double *L, double *Kinv, double *a
     if (beside)
         (void)hipStreamWaitEvent(s, join, 0);
     else
-        hipLaunchKernelGGL(grad_alpha_kernel, dim3((g.n0 + 1 + 3) / 4, Bc), dim3(256), 0, s, g, L,
-                           alpha, quad);
+        hipLaunchKernelGGL(grad_alpha_kernel, agrid, dim3(256), 0, s, g, L, alpha, quad, a_first);
 }
 
 void launch_grad_contract(const JobGeom &g, const ChunkPtrs &p, const double *Kinv,
